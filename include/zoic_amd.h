@@ -1,0 +1,174 @@
+/*
+ * include/zoic_amd.h -- C-ABI of libzoic_amd.so, the MI355X (gfx950) camera-ray generator for
+ * zoic's per-sample lens hot path.
+ *
+ * Drop-in boundary.  zoic is an Arnold camera node: Arnold calls the method table
+ * (AI_CAMERA_NODE_EXPORT_METHODS(zoicMethods), zoic.cpp:61; returned by NodeLoader,
+ * zoic.cpp:1999-2007) -- node_parameters / node_initialize / node_update / node_finish /
+ * camera_create_ray.  Each entry point below replaces one of those methods (file:line cited
+ * per function) with plain pointers and sizes; no C++ or torch types cross this boundary.
+ * INTEGRATION.md shows the binding a zoic maintainer would add inside zoic.cpp.
+ *
+ * All compute entry points run hand-written HIP kernels; there is no CPU fallback.  Every
+ * function returns a zoic_status; ZOIC_OK == 0.
+ */
+#ifndef ZOIC_AMD_H
+#define ZOIC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZOIC_AMD_ABI_VERSION 1
+
+typedef enum zoic_status {
+    ZOIC_OK = 0,
+    ZOIC_ERR_INVALID_ARGUMENT = 1,
+    ZOIC_ERR_LENS_PATH = 2,        /* "[ZOIC] Lens Data Path is invalid"            zoic.cpp:1639-1642 */
+    ZOIC_ERR_LENS_COLUMNS = 3,     /* "<4 / >5 columns of data"                     zoic.cpp:745-754   */
+    ZOIC_ERR_LENS_PARSE = 4,       /* std::stof would throw                         zoic.cpp:774 ff.   */
+    ZOIC_ERR_MULTI_APERTURE = 5,   /* "Multiple apertures found"                    zoic.cpp:926-929   */
+    ZOIC_ERR_NO_APERTURE = 6,      /* no zero-radius row: apertureElement would be read uninitialised (zoic.cpp:922,1115,1668) */
+    ZOIC_ERR_TOO_MANY_LENSES = 7,  /* > ZOIC_MAX_LENS_SURFACES rows */
+    ZOIC_ERR_BOKEH_IMAGE = 8,      /* "[ZOIC] Couldn't open bokeh image!"           zoic.cpp:1589-1592 */
+    ZOIC_ERR_NOT_UPDATED = 9,      /* create_rays before a successful update */
+    ZOIC_ERR_HIP = 10,             /* HIP runtime error; zoic_last_error_string() has the text */
+    ZOIC_ERR_NO_DEVICE = 11        /* no gfx950 device visible: this library has no CPU path */
+} zoic_status;
+
+/* enum LensModel, zoic.cpp:84-88 */
+typedef enum zoic_lens_model { ZOIC_THINLENS = 0, ZOIC_RAYTRACED = 1, ZOIC_LENS_NONE = 2 } zoic_lens_model;
+
+/* arithmetic mode of the kernels */
+typedef enum zoic_precision {
+    ZOIC_PRECISION_STRICT = 0, /* the reference's operation order, no FMA contraction, its f64 intermediates: bit-exact vs the CPU oracle */
+    ZOIC_PRECISION_FAST = 1    /* same algorithm, f32 only, FMA/rsq, redundant normalisations removed: direction RMSE < 1e-5 */
+} zoic_precision;
+
+#define ZOIC_MAX_LENS_SURFACES 32
+#define ZOIC_LUT_ENTRIES 32 /* exitPupilLUT(&ld, 32, 100000), zoic.cpp:1692 */
+
+/* The 14 node parameters: names, types and defaults of node_parameters (zoic.cpp:1547-1562),
+ * read by cameraParams::fromNode (zoic.cpp:578-593). */
+typedef struct zoic_params {
+    float sensorWidth;               /* 3.6  cm */
+    float sensorHeight;              /* 2.4  cm */
+    float focalLength;               /* 2.0  cm */
+    float fStop;                     /* 4.0     */
+    float focalDistance;             /* 100  cm */
+    int32_t useImage;                /* false   */
+    const char *bokehPath;           /* ""  : identity of the bokeh image (change detection, zoic.cpp:608-611);
+                                              a ".pfm" path is loaded from disk unless pixels were supplied by
+                                              zoic_camera_set_bokeh_image */
+    int32_t lensModel;               /* RAYTRACED */
+    const char *lensDataPath;        /* ""  : tabular .dat lens prescription */
+    int32_t kolbSamplingLUT;         /* true    */
+    int32_t useDof;                  /* true    */
+    float opticalVignettingDistance; /* 0.0     */
+    float opticalVignettingRadius;   /* 1.0     */
+    float exposureControl;           /* 0.0     */
+} zoic_params;
+
+/* AtCameraInput / AtCameraOutput (Arnold 5 ai_cameras.h) as PODs; zoic reads
+ * input.{sx,sy,lensx,lensy} and writes output.{origin,dir,weight,dOdy,dDdy} (zoic.cpp:1752-1990). */
+typedef struct zoic_camera_input { float sx, sy, dsx, dsy, lensx, lensy, relative_time; } zoic_camera_input;
+typedef struct zoic_vec3 { float x, y, z; } zoic_vec3;
+typedef struct zoic_camera_output {
+    zoic_vec3 origin, dir, dOdx, dOdy, dDdx, dDdy;
+    float weight[3];
+} zoic_camera_output;
+
+/* Batch output, structure of arrays: 7 planes of n floats + 1 flag byte per ray.
+ * flags: bit0 = retried (tries > 0  => the caller sets dOdy=origin, dDdy=dir, zoic.cpp:1974-1977),
+ *        bits1-5 = tries (0..26; 26 => weight 0, zoic.cpp:1951-1953), bit6 = outside the exit-pupil LUT (fenced UB). */
+typedef struct zoic_ray_planes {
+    float *ox, *oy, *oz;
+    float *dx, *dy, *dz;
+    float *weight;
+    uint8_t *flags;
+} zoic_ray_planes;
+
+/* struct cameraData (zoic.cpp:627-643) + its device tables */
+typedef struct zoic_camera zoic_camera;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int         zoic_abi_version(void);
+const char *zoic_status_string(zoic_status);
+const char *zoic_last_error_string(void);          /* thread-local detail of the last failure */
+int         zoic_device_count(void);               /* gfx950 devices visible to HIP */
+
+/* ---- node lifetime ------------------------------------------------------------------------- */
+/* node_parameters defaults, zoic.cpp:1547-1562 */
+void zoic_params_default(zoic_params *p);
+/* node_initialize, zoic.cpp:1565-1572 (`new cameraData()`); binds the camera to one HIP device */
+zoic_status zoic_camera_create(int device, zoic_camera **out);
+/* node_finish, zoic.cpp:1723-1749 (`delete camera`) */
+void zoic_camera_destroy(zoic_camera *cam);
+/* node_update, zoic.cpp:1575-1720: bokeh CDF build, lens parse + precompute + exit-pupil LUT, upload */
+zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p);
+/* replaces AiTextureGetResolution / AiTextureGetNumChannels / AiTextureLoad (zoic.cpp:101-103,176-186):
+ * the pixels (row-major, nchannels interleaved floats) the next update uses when useImage is set */
+zoic_status zoic_camera_set_bokeh_image(zoic_camera *cam, int width, int height, int nchannels, const float *pixels);
+/* lens prescription text in memory instead of fopen(lensDataPath) (readTabularLensData, zoic.cpp:708-914) */
+zoic_status zoic_camera_set_lens_text(zoic_camera *cam, const char *text, size_t len);
+zoic_status zoic_camera_set_precision(zoic_camera *cam, zoic_precision mode);
+/* seed of the per-ray retry streams (see zoic_create_rays_device) */
+zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed);
+
+/* ---- the hot path: camera_create_ray, zoic.cpp:1752-1990 ----------------------------------- */
+/* n samples already resident in device memory.
+ *   d_samples    : n x (sx, sy, lensx, lensy) f32, 16-byte aligned (AtCameraInput fields zoic reads)
+ *   d_rng_states : NULL, or n x 4 u32 xorshift128 states (zoic.cpp:647-652), one private retry stream per ray.
+ *                  NULL => ray i uses the stream seeded from (seed, ray_index_base + i), so results do not
+ *                  depend on how the image is split over launches or GPUs.
+ *   out          : device pointers; any plane may be NULL (not written)
+ *   stream       : hipStream_t (NULL = default stream).  Asynchronous.
+ * The reference draws retries from ONE process-global stream shared (racily) by all render threads
+ * (zoic.cpp:648); a per-ray stream is the only order-independent restatement. */
+zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng_states,
+                                    uint64_t ray_index_base, zoic_ray_planes out, void *stream);
+/* same, host buffers: H2D, kernels, D2H, synchronous */
+zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_samples, const uint32_t *h_rng_states,
+                                  uint64_t ray_index_base, zoic_ray_planes out);
+/* Arnold-layout batch: n AtCameraInput -> n AtCameraOutput (host).  outputs must arrive initialised the way
+ * Arnold hands them to camera_create_ray (origin 0, weight 1; thin-lens reads output.origin, zoic.cpp:1777). */
+zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_camera_input *inputs,
+                                    zoic_camera_output *outputs, uint64_t ray_index_base);
+/* camera_create_ray(node, input, output, tid): the per-sample signature (n == 1 of the above; latency bound) */
+zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output,
+                                   uint16_t tid);
+
+/* synthetic sample generator used by bench/tests: pixel-jittered screen samples, uniform lens samples */
+zoic_status zoic_generate_samples_device(zoic_camera *cam, uint64_t n, uint64_t ray_index_base, uint32_t width,
+                                         uint32_t height, uint32_t spp, uint32_t seed, float *d_samples, void *stream);
+
+/* ---- statistics (node_finish prints them, zoic.cpp:1729-1732) ------------------------------ */
+typedef struct zoic_counters { uint64_t succesRays, vignettedRays, totalInternalReflection; } zoic_counters;
+zoic_status zoic_camera_get_counters(zoic_camera *cam, zoic_counters *out); /* synchronises the device */
+zoic_status zoic_camera_reset_counters(zoic_camera *cam);
+
+/* ---- introspection of the precomputed tables (parity tests) -------------------------------- */
+typedef struct zoic_lens_info {
+    int32_t lensCount, apertureElement;
+    float userApertureRadius, originShift, apertureDistance, focalLengthRatio;
+    float tracedFocalLength[2];
+    float fov, tan_fov, apertureRadius;            /* thin lens, zoic.cpp:1606-1608 */
+    float curvature[ZOIC_MAX_LENS_SURFACES], thickness[ZOIC_MAX_LENS_SURFACES], ior[ZOIC_MAX_LENS_SURFACES],
+          aperture[ZOIC_MAX_LENS_SURFACES], center[ZOIC_MAX_LENS_SURFACES];
+    int32_t lutSize;
+    float lutKey[ZOIC_LUT_ENTRIES];
+    float lutMaxX[ZOIC_LUT_ENTRIES], lutMaxY[ZOIC_LUT_ENTRIES], lutMinX[ZOIC_LUT_ENTRIES], lutMinY[ZOIC_LUT_ENTRIES];
+    int32_t bokehWidth, bokehHeight;
+} zoic_lens_info;
+zoic_status zoic_camera_get_info(const zoic_camera *cam, zoic_lens_info *out);
+/* copies of the bokeh CDF tables (bokehProbability, zoic.cpp:222-417); arrays sized by bokehWidth/Height */
+zoic_status zoic_camera_get_bokeh_tables(const zoic_camera *cam, float *cdfRow, int32_t *rowIndices, float *cdfColumn,
+                                         int32_t *columnIndices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZOIC_AMD_H */
