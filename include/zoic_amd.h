@@ -49,6 +49,7 @@ typedef enum zoic_precision {
 } zoic_precision;
 
 #define ZOIC_MAX_LENS_SURFACES 32
+#define ZOIC_DEVICE_NONE (-1) /* zoic_camera_create: tables-only camera (host precompute of node_update; cannot make rays) */
 #define ZOIC_LUT_ENTRIES 32 /* exitPupilLUT(&ld, 32, 100000), zoic.cpp:1692 */
 
 /* The 14 node parameters: names, types and defaults of node_parameters (zoic.cpp:1547-1562),
@@ -103,7 +104,10 @@ int         zoic_device_count(void);               /* gfx950 devices visible to 
 /* ---- node lifetime ------------------------------------------------------------------------- */
 /* node_parameters defaults, zoic.cpp:1547-1562 */
 void zoic_params_default(zoic_params *p);
-/* node_initialize, zoic.cpp:1565-1572 (`new cameraData()`); binds the camera to one HIP device */
+/* node_initialize, zoic.cpp:1565-1572 (`new cameraData()`); binds the camera to one HIP device.
+ * device == ZOIC_DEVICE_NONE gives a tables-only camera: update() runs the host precompute (lens parse, focus,
+ * exit-pupil LUT, bokeh CDF) and the get_info/get_bokeh_tables getters work, but every create_rays call fails
+ * with ZOIC_ERR_NO_DEVICE -- there is no CPU ray path. */
 zoic_status zoic_camera_create(int device, zoic_camera **out);
 /* node_finish, zoic.cpp:1723-1749 (`delete camera`) */
 void zoic_camera_destroy(zoic_camera *cam);

@@ -810,7 +810,7 @@ void zo_create_ray(zo_camera *camera, const zo_input *input, zo_output *output, 
     const zo_params *params = &camera->params.p;
     zo_lensdata *ld = &camera->lens;
     if (!rng) rng = &camera->rng;
-    int tries = 0;
+    int tries = 0, lut_miss = 0;
     const int maxtries = 25;
 
     switch (params->lensModel) {
@@ -880,10 +880,12 @@ void zo_create_ray(zo_camera *camera, const zo_input *input, zo_output *output, 
             float sin = zo_fast_sin(theta);
             float cos = zo_fast_cos(theta);
             float maxScale, translation;
-            if (low >= ld->lutSize) {
-                /* lower_bound()==end() is dereferenced at :1896 (UB, d > 3.875 cm).  Fenced: such a
-                 * sample is outside every tabulated image circle; use the all-zero entry semantics. */
+            if (ld->lutSize <= 0 || !(distanceFromOrigin <= ld->lutKeys[ld->lutSize - 1])) {
+                /* lower_bound()==end() is dereferenced at :1896 (UB, d > 3.875 cm; NaN lands here too).
+                 * Fenced: such a sample is outside every tabulated image circle; use the all-zero entry
+                 * semantics and report it (flag bit 6 of the batch driver). */
                 maxScale = 0.0f; translation = 0.0f;
+                lut_miss = 1;
             } else if (low == 0) {
                 /* --begin() at :1905 is UB (d == 0).  Fenced with the reference's own d==0 branch of
                  * testAperturesLUT (zoic.cpp:1512-1518): entry 0, no interpolation. */
@@ -941,7 +943,7 @@ void zo_create_ray(zo_camera *camera, const zo_input *input, zo_output *output, 
     } else if (params->exposureControl < 0.0f) {
         for (int k = 0; k < 3; ++k) output->weight[k] *= 1.0f / (1.0f + e2);
     }
-    if (tries_out) *tries_out = tries;
+    if (tries_out) *tries_out = tries | (lut_miss << 8);
 }
 
 /* ------------------------------------------------------------ batch driver */
@@ -957,7 +959,9 @@ static void one_ray(zo_camera *cam, size_t n, size_t i, const float *in4, float 
     planes[0 * n + i] = out.origin.x; planes[1 * n + i] = out.origin.y; planes[2 * n + i] = out.origin.z;
     planes[3 * n + i] = out.dir.x;    planes[4 * n + i] = out.dir.y;    planes[5 * n + i] = out.dir.z;
     planes[6 * n + i] = out.weight[0];
-    if (flags) flags[i] = (uint8_t)((tries > 0 ? 1 : 0) | (tries << 1));
+    int lut_miss = tries >> 8;
+    tries &= 0xff;
+    if (flags) flags[i] = (uint8_t)((tries > 0 ? 1 : 0) | (tries << 1) | (lut_miss << 6));
     if (tries_out) *tries_out = tries;
 }
 

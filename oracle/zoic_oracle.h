@@ -91,13 +91,13 @@ void zo_camera_set_lens_text(zo_camera *, const char *text, size_t len);
 int zo_camera_update(zo_camera *, const zo_params *);   /* node_update zoic.cpp:1575-1720 */
 
 /* camera_create_ray zoic.cpp:1752-1990.  rng==NULL -> the camera-global stream
- * (reference semantics, single thread).  *tries_out receives `tries`. */
+ * (reference semantics, single thread).  *tries_out receives `tries` | (outside-LUT fence << 8). */
 void zo_create_ray(zo_camera *, const zo_input *in, zo_output *out, zo_rng *rng, int *tries_out);
 
 /* batch driver used by tests / cpu baseline.
  *   in4        : n x (sx, sy, lensx, lensy)
  *   planes     : 7 planes of n floats: ox oy oz dx dy dz weight
- *   flags      : n bytes: bit0 = retried (tries>0), bits1-5 = tries (0..26)
+ *   flags      : n bytes: bit0 = retried (tries>0), bits1-5 = tries (0..26), bit6 = outside the LUT (fenced UB)
  *   rng_states : NULL -> global sequential stream; else n x 4 u32 per-ray states (read only)
  *   first_retry_states : optional out, n x 4 u32: stream state when the ray's first retry drew
  *                        (state before the draw); zeros for rays that never retried */

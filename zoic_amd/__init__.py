@@ -1,0 +1,11 @@
+"""zoic_amd -- MI355X-native camera-ray generator for zoic's per-sample lens hot path.
+
+The product is libzoic_amd.so (HIP kernels + C-ABI, include/zoic_amd.h).  This package is the thin host-side
+mirror of the reference's Arnold node interface over that C-ABI; it contains no ray arithmetic and no CPU
+fallback -- if the library is missing, importing the camera raises.
+"""
+from ._capi import PRECISION_FAST, PRECISION_STRICT, RAYTRACED, THINLENS, ZoicLibraryError  # noqa: F401
+from .camera import DEFAULTS, ZoicCamera, ZoicError, lens_path  # noqa: F401
+
+__all__ = ["ZoicCamera", "ZoicError", "ZoicLibraryError", "DEFAULTS", "lens_path", "RAYTRACED", "THINLENS",
+           "PRECISION_STRICT", "PRECISION_FAST"]

@@ -1,0 +1,53 @@
+"""Build libzoic_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m zoic_amd.build [--force]
+
+The shared library is the product: HIP kernels + the C-ABI of include/zoic_amd.h.  It depends on
+libamdhip64 only (no torch, no Python).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libzoic_amd.so")
+SOURCES = ["capi.cpp", "lens_system.cpp", "kernels.hip", "kolb_fast.hip"]
+HEADERS = ["tables.hpp", "optics.hpp", "lens_system.hpp", "kernels.hpp", os.path.join(ROOT, "include", "zoic_amd.h")]
+
+# -ffp-contract=off: strict kernels and the host precompute must round exactly like the CPU oracle;
+# the fast kernel re-enables contraction locally with a pragma.
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libzoic_amd.so cannot be built (no CPU fallback exists)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

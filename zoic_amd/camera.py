@@ -1,0 +1,250 @@
+"""Host-side mirror of zoic's Arnold camera node over the C-ABI (libzoic_amd.so).
+
+    cam = ZoicCamera(device=0)                       # node_initialize   zoic.cpp:1565-1572
+    cam.update(lensModel=RAYTRACED, lensDataPath=..) # node_update       zoic.cpp:1575-1720 (14 parameters, same names)
+    rays = cam.create_rays(samples)                  # camera_create_ray zoic.cpp:1752-1990, batched
+    cam.close()                                      # node_finish       zoic.cpp:1723-1749
+
+Parameter names, defaults and error behaviour follow node_parameters (zoic.cpp:1547-1562).  Errors the reference
+reports with AiMsgError + AiRenderAbort() surface as ZoicError with the same message text.
+
+This module only marshals pointers; all rays come from the HIP kernels.  torch tensors (device memory) and numpy
+arrays (host memory) are both accepted.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import PRECISION_FAST, PRECISION_STRICT, RAYTRACED, THINLENS  # noqa: F401
+
+LENS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lenses")
+
+# node_parameters, zoic.cpp:1547-1562
+DEFAULTS = dict(sensorWidth=3.6, sensorHeight=2.4, focalLength=2.0, fStop=4.0, focalDistance=100.0, useImage=False,
+                bokehPath="", lensModel=RAYTRACED, lensDataPath="", kolbSamplingLUT=True, useDof=True,
+                opticalVignettingDistance=0.0, opticalVignettingRadius=1.0, exposureControl=0.0)
+_STR = ("bokehPath", "lensDataPath")
+_INT = ("useImage", "lensModel", "kolbSamplingLUT", "useDof")
+
+FLAG_RETRIED = 1
+FLAG_LUT_MISS = 64
+
+
+def lens_path(name):
+    """Path of a bundled lens prescription (zoic_amd/lenses/*.dat)."""
+    p = os.path.join(LENS_DIR, name)
+    if not os.path.exists(p):
+        raise FileNotFoundError(p)
+    return p
+
+
+class ZoicError(RuntimeError):
+    def __init__(self, status, detail):
+        name = _capi.STATUS_NAMES[status] if 0 <= status < len(_capi.STATUS_NAMES) else str(status)
+        super().__init__("%s: %s" % (name, detail))
+        self.status = status
+        self.status_name = name
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class ZoicCamera:
+    def __init__(self, device=0):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        self._h = None
+        self._check(self._lib.zoic_camera_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.params = None
+
+    # ------------------------------------------------------------------ lifetime
+    def _check(self, status):
+        if status != 0:
+            raise ZoicError(status, (self._lib.zoic_last_error_string() or b"").decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zoic_camera_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------ node_update
+    def set_bokeh_image(self, pixels):
+        """pixels: (H, W, C>=3) float32 -- what AiTextureLoad would return for bokehPath (zoic.cpp:176-186)."""
+        px = np.ascontiguousarray(pixels, dtype=np.float32)
+        if px.ndim != 3:
+            raise ValueError("bokeh image must be (H, W, C)")
+        h, w, c = px.shape
+        self._check(self._lib.zoic_camera_set_bokeh_image(self._h, w, h, c, px.ctypes.data))
+
+    def set_lens_text(self, text):
+        if text is None:
+            self._check(self._lib.zoic_camera_set_lens_text(self._h, None, 0))
+            return
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        self._check(self._lib.zoic_camera_set_lens_text(self._h, b, len(b)))
+
+    def set_precision(self, mode):
+        self._check(self._lib.zoic_camera_set_precision(self._h, int(mode)))
+
+    def set_seed(self, seed):
+        self._check(self._lib.zoic_camera_set_seed(self._h, int(seed) & 0xFFFFFFFF))
+
+    def update(self, **kw):
+        unknown = set(kw) - set(DEFAULTS)
+        if unknown:
+            raise KeyError("unknown zoic parameter(s): %s" % sorted(unknown))
+        p = dict(DEFAULTS)
+        p.update(kw)
+        P = _capi.Params()
+        self._keep = []
+        for k, v in p.items():
+            if k in _STR:
+                b = str(v).encode()
+                self._keep.append(b)
+                setattr(P, k, b)
+            elif k in _INT:
+                setattr(P, k, int(v))
+            else:
+                setattr(P, k, float(v))
+        self.params = p
+        self._check(self._lib.zoic_camera_update(self._h, C.byref(P)))
+        return self
+
+    # ------------------------------------------------------------------ camera_create_ray
+    def create_rays(self, samples, rng_states=None, ray_index_base=0, out=None, stream=None):
+        """samples: (n,4) float32 rows (sx, sy, lensx, lensy).
+
+        numpy in -> dict of numpy planes (host API: H2D, kernels, D2H).
+        torch device tensor in -> dict of torch tensors on the same device (device API, asynchronous on `stream`
+        or torch's current stream).
+        """
+        if _is_torch(samples):
+            return self._create_rays_torch(samples, rng_states, ray_index_base, out, stream)
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        if s.ndim != 2 or s.shape[1] != 4:
+            raise ValueError("samples must be (n, 4)")
+        n = s.shape[0]
+        planes = np.empty((7, n), dtype=np.float32)
+        flags = np.empty(n, dtype=np.uint8)
+        rs_ptr = None
+        if rng_states is not None:
+            rs = np.ascontiguousarray(rng_states, dtype=np.uint32)
+            if rs.shape != (n, 4):
+                raise ValueError("rng_states must be (n, 4) uint32")
+            rs_ptr = rs.ctypes.data
+        rp = _capi.RayPlanes(*[planes[k].ctypes.data for k in range(7)], flags.ctypes.data)
+        self._check(self._lib.zoic_create_rays_host(self._h, n, s.ctypes.data, rs_ptr, int(ray_index_base), rp))
+        return dict(planes=planes, origin=planes[0:3], dir=planes[3:6], weight=planes[6], flags=flags,
+                    tries=((flags >> 1) & 31).astype(np.int32))
+
+    def _create_rays_torch(self, samples, rng_states, ray_index_base, out, stream):
+        import torch
+        if samples.dtype != torch.float32 or samples.dim() != 2 or samples.shape[1] != 4 or not samples.is_contiguous():
+            raise ValueError("samples must be a contiguous (n,4) float32 tensor")
+        if not samples.is_cuda:
+            raise ValueError("torch samples must live on the GPU (use numpy for host buffers)")
+        n = samples.shape[0]
+        if out is None:
+            out = dict(planes=torch.empty((7, n), dtype=torch.float32, device=samples.device),
+                       flags=torch.empty(n, dtype=torch.uint8, device=samples.device))
+        planes, flags = out["planes"], out["flags"]
+        rs_ptr = None
+        if rng_states is not None:
+            if rng_states.dtype not in (torch.int32, torch.uint32) or tuple(rng_states.shape) != (n, 4):
+                raise ValueError("rng_states must be (n,4) int32/uint32 on the device")
+            rs_ptr = rng_states.data_ptr()
+        st = stream if stream is not None else torch.cuda.current_stream(samples.device).cuda_stream
+        rp = _capi.RayPlanes(*[planes[k].data_ptr() for k in range(7)], flags.data_ptr())
+        self._check(self._lib.zoic_create_rays_device(self._h, n, samples.data_ptr(), rs_ptr, int(ray_index_base), rp,
+                                                      C.c_void_p(st)))
+        out.update(origin=planes[0:3], dir=planes[3:6], weight=planes[6])
+        return out
+
+    def create_rays_device_ptr(self, n, d_samples, d_planes7, d_flags, d_rng=None, ray_index_base=0, stream=0):
+        """Raw-pointer form of zoic_create_rays_device: d_planes7 is one allocation of 7*n floats."""
+        rp = _capi.RayPlanes(*[d_planes7 + 4 * n * k for k in range(7)], d_flags)
+        self._check(self._lib.zoic_create_rays_device(self._h, n, d_samples, d_rng, int(ray_index_base), rp,
+                                                      C.c_void_p(stream)))
+
+    def create_ray(self, sx, sy, lensx, lensy, tid=0):
+        """The per-sample camera_create_ray(node, input, output, tid) signature (one AtCameraInput in, one AtCameraOutput out)."""
+        i = _capi.CameraInput(sx, sy, 0.0, 0.0, lensx, lensy, 0.0)
+        o = _capi.CameraOutput()
+        o.weight[0] = o.weight[1] = o.weight[2] = 1.0
+        self._check(self._lib.zoic_camera_create_ray(self._h, C.byref(i), C.byref(o), int(tid)))
+        return o
+
+    def create_rays_arnold(self, inputs, ray_index_base=0):
+        """inputs: (n,7) float32 AtCameraInput rows -> (n,21) float32 AtCameraOutput rows (weight initialised to 1)."""
+        a = np.ascontiguousarray(inputs, dtype=np.float32)
+        n = a.shape[0]
+        outs = np.zeros((n, 21), dtype=np.float32)
+        outs[:, 18:21] = 1.0
+        self._check(self._lib.zoic_create_rays_arnold(self._h, n, a.ctypes.data_as(C.POINTER(_capi.CameraInput)),
+                                                      outs.ctypes.data_as(C.POINTER(_capi.CameraOutput)), int(ray_index_base)))
+        return outs
+
+    def generate_samples(self, n, width, height, spp, seed=1, ray_index_base=0, out=None, stream=None):
+        """Synthetic camera samples on the device (torch tensor out)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        self._check(self._lib.zoic_generate_samples_device(self._h, n, int(ray_index_base), width, height, spp, seed,
+                                                           out.data_ptr(), C.c_void_p(st)))
+        return out
+
+    # ------------------------------------------------------------------ statistics / tables
+    def counters(self):
+        c = _capi.Counters()
+        self._check(self._lib.zoic_camera_get_counters(self._h, C.byref(c)))
+        return dict(succesRays=c.succesRays, vignettedRays=c.vignettedRays, totalInternalReflection=c.totalInternalReflection)
+
+    def reset_counters(self):
+        self._check(self._lib.zoic_camera_reset_counters(self._h))
+
+    def info(self):
+        i = _capi.LensInfo()
+        self._check(self._lib.zoic_camera_get_info(self._h, C.byref(i)))
+        n = i.lensCount
+        f = lambda a, m: np.array(a[:m], dtype=np.float32)  # noqa: E731
+        elements = np.stack([f(i.curvature, n), f(i.thickness, n), f(i.ior, n), f(i.aperture, n), f(i.center, n)], 1) \
+            if n else np.zeros((0, 5), np.float32)
+        return dict(lensCount=n, apertureElement=i.apertureElement, elements=elements,
+                    userApertureRadius=np.float32(i.userApertureRadius), originShift=np.float32(i.originShift),
+                    apertureDistance=np.float32(i.apertureDistance), focalLengthRatio=np.float32(i.focalLengthRatio),
+                    tracedFocalLength=(np.float32(i.tracedFocalLength[0]), np.float32(i.tracedFocalLength[1])),
+                    fov=np.float32(i.fov), tan_fov=np.float32(i.tan_fov), apertureRadius=np.float32(i.apertureRadius),
+                    lutKeys=f(i.lutKey, i.lutSize),
+                    lutBoxes=np.stack([f(i.lutMaxX, i.lutSize), f(i.lutMaxY, i.lutSize), f(i.lutMinX, i.lutSize),
+                                       f(i.lutMinY, i.lutSize)], 1),
+                    bokehWidth=i.bokehWidth, bokehHeight=i.bokehHeight)
+
+    def bokeh_tables(self):
+        i = self.info()
+        x, y = i["bokehWidth"], i["bokehHeight"]
+        if x <= 0 or y <= 0:
+            return None
+        t = dict(x=x, y=y, cdfRow=np.empty(y, np.float32), rowIndices=np.empty(y, np.int32),
+                 cdfColumn=np.empty(x * y, np.float32), columnIndices=np.empty(x * y, np.int32))
+        self._check(self._lib.zoic_camera_get_bokeh_tables(self._h, t["cdfRow"].ctypes.data, t["rowIndices"].ctypes.data,
+                                                           t["cdfColumn"].ctypes.data, t["columnIndices"].ctypes.data))
+        return t

@@ -1,0 +1,287 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for zoic's per-sample lens hot path, STRICT mode,
+// plus the small service kernels (sample synthesis, exit-pupil LUT probes, Arnold AoS packing).
+//
+// Mapping (DESIGN.md "kernels"): one camera sample per lane, 256-lane workgroups (4 waves = one per SIMD),
+// a grid capped at 8 workgroups per CU that strides over the sample buffer.  The lens prescription and the
+// exit-pupil LUT arrive as a by-value kernel argument: wave-uniform, fetched by s_load through the scalar
+// cache, indexed by the (uniform) surface counter -- no LDS and no VGPRs spent on tables.  Sample loads are
+// one 16-byte global_load_dwordx4 per lane (1 KiB per wave instruction); results leave as seven coalesced
+// 4-byte planes + a flag byte.  The path is scalar FP32 per ray: no contraction to feed MFMA.
+//
+// STRICT = the reference's operation order and f64 intermediates, no FMA contraction (see optics.hpp): bit-exact
+// against the CPU oracle.  The FAST variant lives in kolb_fast.hip.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "optics.hpp"
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace zoic {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ void store_ray(const RayPlanes &out, uint64_t i, V3 o, V3 d, float w, uint8_t flags)
+{
+    if (out.ox) out.ox[i] = o.x;
+    if (out.oy) out.oy[i] = o.y;
+    if (out.oz) out.oz[i] = o.z;
+    if (out.dx) out.dx[i] = d.x;
+    if (out.dy) out.dy[i] = d.y;
+    if (out.dz) out.dz[i] = d.z;
+    if (out.weight) out.weight[i] = w;
+    if (out.flags) out.flags[i] = flags;
+}
+
+// sum three per-lane counters over the workgroup, one atomic per counter per workgroup
+__device__ __forceinline__ void flush_counters(DeviceCounters *c, uint32_t succ, uint32_t vign, uint32_t tir)
+{
+    if (!c) return;
+    __shared__ uint32_t part[3][kBlock / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        succ += __shfl_down(succ, off, 64);
+        vign += __shfl_down(vign, off, 64);
+        tir += __shfl_down(tir, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { part[0][wave] = succ; part[1][wave] = vign; part[2][wave] = tir; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long s = 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += part[threadIdx.x][w];
+        unsigned long long *dst = threadIdx.x == 0 ? &c->succes : (threadIdx.x == 1 ? &c->vignetted : &c->tir);
+        if (s) atomicAdd(dst, s);
+    }
+}
+
+__device__ __forceinline__ V2 sample_lens(bool useImage, const BokehTables &B, int bw, int bh, float u, float v)
+{
+    if (useImage) return bokeh_sample(B.cdfRow, B.rowIndices, B.cdfColumn, B.columnIndices, bw, bh, u, v);
+    return concentric_disk(u, v);
+}
+
+// ------------------------------------------------------------------------------------- RAYTRACED, strict
+__global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTable T, const BokehTables B,
+                                                                  const float4 *__restrict__ samples,
+                                                                  const uint4 *__restrict__ rngStates, uint64_t rayBase,
+                                                                  uint64_t n, const RayPlanes out, DeviceCounters *counters)
+{
+    uint32_t succ = 0, vign = 0, tir = 0;
+    const bool useImage = T.useImage != 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const float4 s = samples[i];  // (sx, sy, lensx, lensy)
+        Rng rng;
+        if (rngStates) { const uint4 r = rngStates[i]; rng = Rng{r.x, r.y, r.z, r.w}; }
+        else rng = rng_for_ray(T.seed, rayBase + i);
+
+        // sensor point, zoic.cpp:1853-1855
+        const V3 o0{s.x * T.halfSensor, s.y * T.halfSensor, T.originShift};
+        V2 lens = sample_lens(useImage, B, T.bokehW, T.bokehH, s.z, s.w);  // zoic.cpp:1870
+        float maxScale = 0.0f, translation = 0.0f, sn = 0.0f, cs = 1.0f;
+        uint32_t lutMiss = 0;
+        V3 o = o0, d;
+        if (!T.useLUT) {  // zoic.cpp:1873-1877
+            d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+        } else {          // zoic.cpp:1889-1925
+            const float dist = fabsf(sqrtf(o.x * o.x + o.y * o.y));
+            const float theta = static_cast<float>(atan2(static_cast<double>(o.y), static_cast<double>(o.x)));
+            sn = fast_sin(theta);
+            cs = fast_cos(theta);
+            lutMiss = lut_lookup(T, dist, maxScale, translation) ? 0u : 1u;
+            lens.x *= maxScale; lens.y *= maxScale;
+            lens.x += translation;
+            const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
+            d = V3{rx - o.x, ry - o.y, T.dirZ};
+        }
+        int tries = 0;
+        while (!trace_lens_strict(T, o, d, tir) && tries <= kMaxTries) {  // zoic.cpp:1879 / 1927
+            o = o0;
+            const float u = rng_unit(xor128(rng));
+            const float v = rng_unit(xor128(rng));
+            lens = sample_lens(useImage, B, T.bokehW, T.bokehH, u, v);
+            if (!T.useLUT) {
+                d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+            } else {
+                lens.x *= maxScale; lens.y *= maxScale;
+                lens.x += translation; lens.y += translation;  // both components on retries, zoic.cpp:1933
+                const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
+                d = V3{rx - o.x, ry - o.y, T.dirZ};
+            }
+            ++tries;
+        }
+        float w = 1.0f;
+        if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
+        if (T.exposureOn) w *= T.exposureMul;                      // zoic.cpp:1981-1987
+        const V3 oo{o.x * -1.0f, o.y * -1.0f, o.z * -1.0f};        // zoic.cpp:1960-1961
+        const V3 dd{d.x * -1.0f, d.y * -1.0f, d.z * -1.0f};
+        store_ray(out, i, oo, dd, w, static_cast<uint8_t>((tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1) | (lutMiss << 6)));
+    }
+    flush_counters(counters, succ, vign, tir);
+}
+
+// ------------------------------------------------------------------------------------- THINLENS
+// zoic.cpp:1771-1846 + empericalOpticalVignetting zoic.cpp:1297-1305.  All f32; ~60 flop / 44 B: HBM-bound.
+__device__ __forceinline__ bool optical_vignet_pass(const ThinTable &T, V3 origin, V3 dir)
+{
+    const V3 p{dir.x * T.ovDistance - origin.x, dir.y * T.ovDistance - origin.y, dir.z * T.ovDistance - origin.z};
+    const float hyp = sqrtf((p.x * p.x) + (p.y * p.y));
+    return fabsf(hyp) < T.apertureRadius * T.ovRadius;
+}
+
+__global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, const BokehTables B,
+                                                           const float4 *__restrict__ samples,
+                                                           const uint4 *__restrict__ rngStates, uint64_t rayBase, uint64_t n,
+                                                           const RayPlanes out, DeviceCounters *counters)
+{
+    uint32_t succ = 0, vign = 0;
+    const bool useImage = T.useImage != 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const float4 s = samples[i];
+        Rng rng;
+        if (rngStates) { const uint4 r = rngStates[i]; rng = Rng{r.x, r.y, r.z, r.w}; }
+        else rng = rng_for_ray(T.seed, rayBase + i);
+        const V3 p{s.x * T.tanFov, s.y * T.tanFov, 1.0f};
+        const V3 originOriginal{0.0f, 0.0f, 0.0f};  // Arnold hands output.origin in as 0 (zoic.cpp:1777 reads it)
+        const V3 dir0 = normalize3(V3{p.x - originOriginal.x, p.y - originOriginal.y, p.z - originOriginal.z});
+        V3 origin = originOriginal, dir = dir0;
+        int tries = 0;
+        float w = 1.0f;
+        if (T.useDof) {
+            V2 lens = sample_lens(useImage, B, T.bokehW, T.bokehH, s.z, s.w);
+            lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
+            origin = V3{lens.x, lens.y, 0.0f};
+            const float inter = fabsf(T.focalDistance / dir0.z);
+            const V3 fp{dir0.x * inter, dir0.y * inter, dir0.z * inter};
+            dir = normalize3(V3{fp.x - origin.x, fp.y - origin.y, fp.z - origin.z});
+            if (T.ovDistance > 0.0f) {
+                while (!optical_vignet_pass(T, origin, dir) && tries <= kMaxTries) {  // zoic.cpp:1804-1819
+                    const float u = rng_unit(xor128(rng));
+                    const float v = rng_unit(xor128(rng));
+                    lens = sample_lens(useImage, B, T.bokehW, T.bokehH, u, v);
+                    lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
+                    origin = V3{lens.x, lens.y, 0.0f};
+                    dir = normalize3(V3{fp.x - origin.x, fp.y - origin.y, fp.z - origin.z});  // dir0, inter, fp are loop invariant
+                    ++tries;
+                }
+            }
+            if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1824-1830
+        }
+        dir.z = dir.z * -1.0f;                     // zoic.cpp:1845
+        if (T.exposureOn) w *= T.exposureMul;
+        store_ray(out, i, origin, dir, w, static_cast<uint8_t>((tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1)));
+    }
+    flush_counters(counters, succ, vign, 0u);
+}
+
+// ------------------------------------------------------------------------------------- synthetic samples
+__device__ __forceinline__ float u01_24(uint32_t h) { return static_cast<float>(h >> 8) * 5.9604644775390625e-08f; }
+
+__global__ __launch_bounds__(kBlock) void generate_samples_kernel(float4 *__restrict__ samples, uint64_t rayBase, uint64_t n,
+                                                                  uint32_t W, uint32_t H, uint32_t spp, uint32_t seed)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    const float fW = static_cast<float>(W), fH = static_cast<float>(H);
+    const float aspect = fW / fH;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t id = rayBase + i;
+        const uint64_t pix = id / spp;
+        const uint32_t px = static_cast<uint32_t>(pix % W), py = static_cast<uint32_t>((pix / W) % H);
+        const uint32_t lo = static_cast<uint32_t>(id), hi = static_cast<uint32_t>(id >> 32);
+        const uint32_t key = seed ^ pcg_hash(hi ^ 0x632BE5ABu);
+        const float jx = u01_24(pcg_hash(key ^ (lo * 4u + 0u)));
+        const float jy = u01_24(pcg_hash(key ^ (lo * 4u + 1u) ^ 0x85EBCA6Bu));
+        const float lx = u01_24(pcg_hash(key ^ (lo * 4u + 2u) ^ 0xC2B2AE35u));
+        const float ly = u01_24(pcg_hash(key ^ (lo * 4u + 3u) ^ 0x27D4EB2Fu));
+        const float sx = 2.0f * (static_cast<float>(px) + jx) / fW - 1.0f;
+        const float sy = (1.0f - 2.0f * (static_cast<float>(py) + jy) / fH) / aspect;
+        samples[i] = make_float4(sx, sy, lx, ly);
+    }
+}
+
+// ------------------------------------------------------------------------------------- exit-pupil LUT probes
+__global__ __launch_bounds__(kBlock) void lut_probe_kernel(const KolbTable T, float originX, const float *__restrict__ lensU,
+                                                           const float *__restrict__ lensV, uint64_t n,
+                                                           uint8_t *__restrict__ accepted, unsigned int *tirOut)
+{
+    uint32_t tir = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        V3 o{originX, 0.0f, T.originShift};
+        V3 d{(lensU[i] * T.rearAperture) - originX, (lensV[i] * T.rearAperture) - 0.0f, T.dirZ};
+        accepted[i] = trace_lens_strict(T, o, d, tir) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) tir += __shfl_down(tir, off, 64);
+    if ((threadIdx.x & 63) == 0 && tir && tirOut) atomicAdd(tirOut, tir);
+}
+
+// ------------------------------------------------------------------------------------- Arnold AoS packing
+__global__ __launch_bounds__(kBlock) void pack_inputs_kernel(const float *__restrict__ in7, float4 *__restrict__ out4, uint64_t n)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        const float *p = in7 + i * 7;  // sx sy dsx dsy lensx lensy relative_time
+        out4[i] = make_float4(p[0], p[1], p[4], p[5]);
+    }
+}
+
+// ------------------------------------------------------------------------------------- launchers
+static inline unsigned grid_for(uint64_t n)
+{
+    // 256 CUs x 8 workgroups of 256 lanes = every wave slot of the chip (32 waves/CU); grid-stride the rest
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    return static_cast<unsigned>(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
+}
+
+int launch_kolb_fast(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream);
+
+int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, bool fast, void *stream)
+{
+    if (n == 0) return 0;
+    if (fast) return launch_kolb_fast(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, stream);
+    hipLaunchKernelGGL(kolb_rays_strict_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,
+                       reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,
+                       d_counters);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(thin_rays_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,
+                       reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,
+                       d_counters);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_generate_samples(float *d_samples, uint64_t rayBase, uint64_t n, uint32_t width, uint32_t height, uint32_t spp,
+                            uint32_t seed, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(generate_samples_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<float4 *>(d_samples), rayBase, n, width, height, spp, seed);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_lut_probes(const KolbTable &table, float originX, const float *d_lensU, const float *d_lensV, uint64_t n,
+                      uint8_t *d_accepted, unsigned int *d_tir, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(lut_probe_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, originX,
+                       d_lensU, d_lensV, n, d_accepted, d_tir);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_pack_inputs(const float *d_inputs7, float *d_samples4, uint64_t n, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_inputs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_inputs7,
+                       reinterpret_cast<float4 *>(d_samples4), n);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace zoic

@@ -1,0 +1,38 @@
+// kernels.hpp -- host-callable launchers of the HIP kernels (kernels.hip).  Plain C++ types only.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "tables.hpp"
+
+namespace zoic {
+
+struct RayPlanes {  // device pointers, any may be null
+    float *ox, *oy, *oz, *dx, *dy, *dz, *weight;
+    uint8_t *flags;
+};
+
+struct DeviceCounters {  // zoic.cpp:533-534: succesRays, vignettedRays, totalInternalReflection
+    unsigned long long succes, vignetted, tir;
+};
+
+// camera_create_ray, RAYTRACED branch (zoic.cpp:1850-1964) over n samples.  fast=false: strict arithmetic.
+int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, bool fast, void *stream);
+
+// camera_create_ray, THINLENS branch (zoic.cpp:1771-1846)
+int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream);
+
+// synthetic camera samples: id=(py*W+px)*spp+s, pcg-hashed jitter and lens samples
+int launch_generate_samples(float *d_samples, uint64_t rayBase, uint64_t n, uint32_t width, uint32_t height, uint32_t spp,
+                            uint32_t seed, void *stream);
+
+// exit-pupil LUT probes (traceThroughLensElementsForApertureSize, zoic.cpp:1309-1350) for one film position
+int launch_lut_probes(const KolbTable &table, float originX, const float *d_lensU, const float *d_lensV, uint64_t n,
+                      uint8_t *d_accepted, unsigned int *d_tir, void *stream);
+
+// Arnold AoS <-> planes (AtCameraInput 28 B -> sample 16 B; planes -> AtCameraOutput 84 B)
+int launch_pack_inputs(const float *d_inputs7, float *d_samples4, uint64_t n, void *stream);
+
+}  // namespace zoic

@@ -1,0 +1,82 @@
+// lens_system.hpp -- host side of node_update for the RAYTRACED model (zoic.cpp:1612-1711): parse the tabular
+// lens prescription, normalise it, rescale it to the requested focal length, focus it, and build the
+// exit-pupil LUT.  Produces the KolbTable the HIP kernels take as a kernel argument.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "optics.hpp"
+#include "tables.hpp"
+
+namespace zoic {
+
+enum class LensError {
+    None = 0,
+    Columns,        // zoic.cpp:745-754
+    Parse,          // std::stof would throw, zoic.cpp:774 ff.
+    MultiAperture,  // zoic.cpp:926-929
+    NoAperture,     // apertureElement never written (zoic.cpp:922) -> reading it is UB: rejected
+    TooManySurfaces
+};
+
+// One row of the prescription after parsing (LensElement, zoic.cpp:522-525)
+struct LensRow {
+    float radius = 0, thickness = 0, ior = 0, aperture = 0, abbe = 0, center = 0;
+};
+
+struct LutBox { float maxX = 0, maxY = 0, minX = 0, minY = 0; };  // boundingBox2d, zoic.cpp:490-493
+
+// Accept/reject of one batch of exit-pupil probe rays.  The default implementation traces on the host;
+// the GPU build swaps in a kernel launch (same strict arithmetic) -- see capi.cpp.
+using LutTraceFn = void (*)(const KolbTable &table, float originX, const float *lensU, const float *lensV, size_t n,
+                            uint8_t *accepted, uint32_t *tirCount, void *user);
+
+class LensSystem {
+public:
+    // readTabularLensData, zoic.cpp:708-914
+    LensError parse(const char *text, size_t len);
+    // cleanupLensData .. computeLensCenters (+ exitPupilLUT when useLUT), zoic.cpp:1648-1692.
+    // `rng` is the process-wide xorshift128 stream the LUT build draws from (zoic.cpp:1411-1412).
+    LensError prepare(float focalLength, float fStop, float focalDistance, bool useLUT, Rng &rng,
+                      LutTraceFn trace = nullptr, void *traceUser = nullptr);
+    // flatten for the kernels
+    void fill_table(KolbTable &t, float sensorWidth) const;
+
+    std::vector<LensRow> rows;       // rear -> front after parse()
+    int apertureElement = -1;
+    float userApertureRadius = 0, originShift = 0, apertureDistance = 0, focalLengthRatio = 0;
+    float tracedFocalLength[2] = {0, 0};
+    uint32_t precomputeTIR = 0;      // ld->totalInternalReflection bumps during precompute
+    bool hasLUT = false;
+    float lutKey[kLutEntries] = {};
+    LutBox lutBox[kLutEntries];
+
+private:
+    float trace_focal_length();                       // traceThroughLensElementsForFocalLength, zoic.cpp:1161-1228
+    float image_distance(float objectDistance);       // calculateImageDistance, zoic.cpp:1054-1095
+    void build_lut(Rng &rng, LutTraceFn trace, void *user);  // exitPupilLUT, zoic.cpp:1391-1452
+    void fill_surfaces(KolbTable &t) const;
+};
+
+// host accept/reject (reference behaviour of traceThroughLensElementsForApertureSize, zoic.cpp:1309-1350)
+void lut_trace_host(const KolbTable &table, float originX, const float *lensU, const float *lensV, size_t n,
+                    uint8_t *accepted, uint32_t *tirCount, void *user);
+
+// imageData::bokehProbability, zoic.cpp:222-417.  Ties in the two descending sorts (std::sort is unstable) are
+// broken by ascending index -- the rule the oracle documents.
+struct BokehCdf {
+    int x = 0, y = 0;
+    std::vector<float> cdfRow, cdfColumn;
+    std::vector<int32_t> rowIndices, columnIndices;
+    bool valid() const { return x > 0 && y > 0; }
+    // pixels: row-major, nchannels interleaved floats (what AiTextureLoad(path, true, 0, buf) fills, zoic.cpp:101-103)
+    bool build(const float *pixels, int width, int height, int nchannels);
+    void clear();
+};
+
+// minimal .pfm reader for bokehPath (the reference loads through Arnold's texture system, absent here)
+bool read_pfm(const std::string &path, std::vector<float> &pixels, int &w, int &h, int &nc);
+
+}  // namespace zoic

@@ -1,0 +1,78 @@
+// tables.hpp -- the wave-uniform constant tables the ray kernels read.
+//
+// One KolbTable (< 2 KB) is passed BY VALUE as a kernel argument: every field is wave-uniform, so the
+// compiler fetches it with s_load into SGPRs through the scalar cache -- no VGPRs, no LDS traffic, and the
+// per-surface loop index is uniform, so `surf[i]` stays a scalar load.  (LDS is used only where lanes index
+// divergently: the bokeh row CDF.)
+//
+// Reference structures flattened here: LensElement / Lensdata (zoic.cpp:522-541), the
+// std::map<float,boundingBox2d> exit-pupil LUT (zoic.cpp:540, 1391-1452), cameraData's thin-lens
+// scalars (zoic.cpp:627-630) and the parameters camera_create_ray reads (zoic.cpp:1752-1990).
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define ZOIC_HD __host__ __device__ inline
+#else
+#define ZOIC_HD inline
+#endif
+
+namespace zoic {
+
+constexpr int kMaxSurfaces = 32;
+constexpr int kLutEntries = 32;
+constexpr int kMaxTries = 25;  // const int maxtries = 25, zoic.cpp:1767
+
+// One spherical interface, rear -> front order (index 0 = rear-most, zoic.cpp:913).
+struct Surface {
+    float center;     // sphere centre z, computeLensCenters zoic.cpp:963-969
+    float radius;     // signed radius of curvature (cm, after mm->cm and focal-length rescale)
+    float radius2;    // radius*radius in f32, as raySphereIntersection computes it (zoic.cpp:978)
+    float sign;       // radius < 0 ? -1 : 1 (zoic.cpp:986, 1000)
+    float eta;        // ior2 == 1.0 ? ior1 : ior1/ior2 (zoic.cpp:1013), ior2 = next surface's ior, 1.0 after the last
+    float housing2;   // largest f32 <= ((double)aperture*0.5)^2: `h2 > housing2` in f32 == the f64 compare of zoic.cpp:1114
+    float invRadius;  // 1/radius (fast mode: unit normal = (c - hit) * invRadius)
+    uint32_t tirPossible;  // ior1 > ior2 (zoic.cpp:1019)
+};
+
+struct KolbTable {
+    int32_t lensCount;
+    int32_t apertureElement;
+    float userAperture2;  // userApertureRadius^2 in f32 (zoic.cpp:1115)
+    float originShift;    // sensor z (zoic.cpp:1855)
+    float dirZ;           // -lenses[0].thickness (zoic.cpp:1924)
+    float rearAperture;   // lenses[0].aperture: LUT-off sampling scale (zoic.cpp:1874-1875)
+    float halfSensor;     // sensorWidth*0.5, exact in f32 (zoic.cpp:1853-1854)
+    int32_t useLUT;       // kolbSamplingLUT
+    int32_t useImage;     // image-based bokeh lens sampling
+    int32_t bokehW, bokehH;
+    int32_t lutSize;
+    float exposureMul;    // 1+e^2, 1/(1+e^2) or 1 (zoic.cpp:1981-1987)
+    int32_t exposureOn;
+    uint32_t seed;
+    int32_t pad0;
+    Surface surf[kMaxSurfaces];
+    float lutMaxScale[kLutEntries];  // boundingBox2d::getMaxScale per LUT entry (zoic.cpp:503-517)
+    float lutCentroidX[kLutEntries]; // boundingBox2d::getCentroid().x          (zoic.cpp:495-498)
+};
+
+struct ThinTable {
+    float tanFov;          // zoic.cpp:1607
+    float apertureRadius;  // zoic.cpp:1608
+    float focalDistance;
+    float ovDistance, ovRadius;  // opticalVignettingDistance / Radius
+    int32_t useDof, useImage, bokehW, bokehH;
+    float exposureMul;
+    int32_t exposureOn;
+    uint32_t seed;
+};
+
+// device pointers of the bokeh CDF tables (bokehProbability, zoic.cpp:222-417)
+struct BokehTables {
+    const float *cdfRow;          // y
+    const int32_t *rowIndices;    // y
+    const float *cdfColumn;       // x*y
+    const int32_t *columnIndices; // x*y
+};
+
+}  // namespace zoic
