@@ -1,0 +1,187 @@
+"""Host logic of node_update (product, csrc/lens_system.cpp via a tables-only camera) against the oracle:
+lens parse, precompute chain, exit-pupil LUT, bokeh CDF tables, parameter/error behaviour.  No GPU needed:
+a ZOIC_DEVICE_NONE camera runs the host precompute only and refuses to make rays."""
+import numpy as np
+import pytest
+
+from zoic_amd import RAYTRACED, THINLENS, ZoicCamera, ZoicError, lens_path
+from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh
+
+LENSES_WITH_STOP = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat",
+                    "triplet_f2.5.dat", "mori_f2.8.dat"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same_tables(pc, oc):
+    pi, ot = pc.info(), oc.lens_table()
+    assert pi["lensCount"] == ot["lensCount"] and pi["apertureElement"] == ot["apertureElement"]
+    assert np.array_equal(bits(pi["elements"]), bits(ot["elements"]))
+    for k in ("userApertureRadius", "originShift", "apertureDistance", "focalLengthRatio"):
+        assert bits(pi[k]) == bits(ot[k]), k
+    assert np.array_equal(bits(pi["tracedFocalLength"]), bits(ot["tracedFocalLength"]))
+    ok, ob = oc.lut()
+    assert np.array_equal(pi["lutKeys"], ok)
+    assert np.array_equal(bits(pi["lutBoxes"]), bits(ob))
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
+def test_baseline_configs_tables_bit_exact(oracle_lib, cfg):
+    p = camera_params(cfg)
+    pc, oc = ZoicCamera(device=-1), oracle_lib.OracleCamera()
+    if CONFIGS[cfg]["bokeh"]:
+        img = hexagon_bokeh()
+        pc.set_bokeh_image(img)
+        oc.set_bokeh_image(img)
+    pc.update(**p)
+    oc.update(**p)
+    assert_same_tables(pc, oc)
+    # precompute TIR bumps (ld->totalInternalReflection during the LUT build) agree
+    assert pc.counters()["totalInternalReflection"] == oc.counters()["totalInternalReflection"]
+    if CONFIGS[cfg]["bokeh"]:
+        a, b = pc.bokeh_tables(), oc.bokeh_tables()
+        assert a["x"] == b["x"] == 256 and a["y"] == b["y"] == 256
+        for k in ("rowIndices", "columnIndices"):
+            assert np.array_equal(a[k], b[k]), k
+        for k in ("cdfRow", "cdfColumn"):
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
+        assert np.all(np.diff(a["cdfRow"]) >= 0)
+
+
+@pytest.mark.parametrize("lens", ["triplet_f2.5.dat", "mori_f2.8.dat"])
+def test_other_lenses_no_lut(oracle_lib, lens):
+    kw = dict(lensDataPath=lens_path(lens), focalLength=3.5, fStop=5.6, focalDistance=250.0, kolbSamplingLUT=False)
+    pc, oc = ZoicCamera(device=-1).update(**kw), oracle_lib.OracleCamera().update(**kw)
+    assert_same_tables(pc, oc)
+    assert pc.info()["lutKeys"].size == 0
+
+
+def test_thinlens_scalars(oracle_lib):
+    p = camera_params("C1")
+    pc, oc = ZoicCamera(device=-1).update(**p), oracle_lib.OracleCamera().update(**p)
+    i, t = pc.info(), oc.thinlens()
+    for a, b in (("fov", "fov"), ("tan_fov", "tan_fov"), ("apertureRadius", "apertureRadius")):
+        assert bits(i[a]) == bits(t[b])
+    assert abs(float(i["tan_fov"]) - 0.36) < 1e-6  # sensorWidth/(2*focalLength)
+
+
+def test_lens_without_stop_is_rejected(oracle_lib):
+    """PETZVAL-1.6 and TELEPHOTO have no zero-radius row: the reference then reads apertureElement uninitialised
+    (zoic.cpp:922 is its only write).  Both implementations refuse instead."""
+    for lens in ("petzval_f1.6.dat", "telephoto_f5.0.dat"):
+        with pytest.raises(ZoicError) as e:
+            ZoicCamera(device=-1).update(lensDataPath=lens_path(lens))
+        assert e.value.status_name == "ZOIC_ERR_NO_APERTURE"
+        with pytest.raises(oracle_lib.OracleError) as e2:
+            oracle_lib.OracleCamera().update(lensDataPath=lens_path(lens))
+        assert e2.value.code == 4
+
+
+def test_error_codes_mirror_reference_aborts(oracle_lib):
+    cam = ZoicCamera(device=-1)
+    with pytest.raises(ZoicError) as e:   # zoic.cpp:1639-1642
+        cam.update(lensDataPath="")
+    assert e.value.status_name == "ZOIC_ERR_LENS_PATH" and "Lens Data Path is invalid" in str(e.value)
+    with pytest.raises(ZoicError) as e:
+        cam.update(lensDataPath="/nonexistent/lens.dat")
+    assert e.value.status_name == "ZOIC_ERR_LENS_PATH"
+    cam.set_lens_text("1 2 3\n4 5 6\n")           # 3 columns, zoic.cpp:745-749
+    with pytest.raises(ZoicError) as e:
+        cam.update()
+    assert e.value.status_name == "ZOIC_ERR_LENS_COLUMNS"
+    cam.set_lens_text("1 2 3 4 5 6\n1 2 3 4 5 6\n")  # 6 columns, zoic.cpp:750-754
+    with pytest.raises(ZoicError) as e:
+        cam.update()
+    assert e.value.status_name == "ZOIC_ERR_LENS_COLUMNS"
+    cam.set_lens_text("10 1 1.5 5\n0 1 0 4\n0 1 0 4\n-10 20 0 5\n")  # two stops, zoic.cpp:926-929
+    with pytest.raises(ZoicError) as e:
+        cam.update()
+    assert e.value.status_name == "ZOIC_ERR_MULTI_APERTURE" and "Multiple apertures" in str(e.value)
+    cam.set_lens_text("10 1 abc 5\n0 1 0 4\n-10 20 0 5\n")  # std::stof would throw
+    with pytest.raises(ZoicError) as e:
+        cam.update()
+    assert e.value.status_name == "ZOIC_ERR_LENS_PARSE"
+    cam.set_lens_text("# only comments\n\n")
+    with pytest.raises(ZoicError) as e:
+        cam.update()
+    assert e.value.status_name == "ZOIC_ERR_LENS_COLUMNS"
+    with pytest.raises(ZoicError) as e:   # zoic.cpp:1589-1592
+        ZoicCamera(device=-1).update(lensModel=THINLENS, useImage=True, bokehPath="/nonexistent.pfm")
+    assert e.value.status_name == "ZOIC_ERR_BOKEH_IMAGE" and "Couldn't open bokeh image" in str(e.value)
+    with pytest.raises(KeyError):
+        cam.update(notAParameter=1)
+
+
+@pytest.mark.parametrize("text", [
+    # 4 columns, mixed delimiters from the reference's set "\t,;: ", no trailing newline, blank + comment lines
+    "# hdr\n\n40.0,2.0;1.6:20.0\n-200.0 3.0\t0.0,20.0\n0 5.0 0 12.0\n60.0\t2.0\t1.7\t14.0\n-60.0\t50.0\t0.0\t14.0",
+    # 5 columns (abbe ignored), trailing delimiter on a row
+    "40.0\t2.0\t1.6\t55.0\t20.0\n-200.0\t3.0\t0.0\t0.0\t20.0\t\n0\t5.0\t0\t0\t12.0\n60.0\t2.0\t1.7\t30.0\t14.0\n-60.0\t50.0\t0.0\t0.0\t14.0\n",
+    # doubled delimiter: the reference's cursor advances on the empty token and shifts the fields (zoic.cpp:788-789)
+    "40.0\t2.0\t1.6\t20.0\n-200.0\t\t3.0\t0.0\t20.0\n0\t5.0\t0\t12.0\n60.0\t2.0\t1.7\t14.0\n-60.0\t50.0\t0.0\t14.0\n",
+])
+def test_parser_quirks_match_oracle(oracle_lib, text):
+    kw = dict(focalLength=5.0, fStop=4.0, focalDistance=150.0, kolbSamplingLUT=False)
+    pc, oc = ZoicCamera(device=-1), oracle_lib.OracleCamera()
+    pc.set_lens_text(text)
+    oc.set_lens_text(text)
+    perr = oerr = None
+    try:
+        pc.update(**kw)
+    except ZoicError as e:
+        perr = e.status_name
+    try:
+        oc.update(**kw)
+    except oracle_lib.OracleError as e:
+        oerr = oracle_lib.ERR_NAMES[e.code]
+    assert (perr is None) == (oerr is None), (perr, oerr)
+    if perr is None:
+        assert_same_tables(pc, oc)
+    else:
+        assert perr.replace("ZOIC_ERR_", "") == oerr
+
+
+def test_update_skips_rebuild_when_lens_unchanged(oracle_lib):
+    """lensChanged() false -> the lens tables are kept (zoic.cpp:1615, 1708-1710) and the xor128 stream does not advance."""
+    p = camera_params("C2")
+    pc = ZoicCamera(device=-1).update(**p)
+    before = pc.info()["lutBoxes"].copy()
+    pc.update(**dict(p, exposureControl=1.5, opticalVignettingRadius=2.0))
+    assert np.array_equal(before, pc.info()["lutBoxes"])
+    # a real change rebuilds, continuing the same stream (second LUT differs from a fresh camera's)
+    pc.update(**dict(p, fStop=4.0))
+    fresh = ZoicCamera(device=-1).update(**dict(p, fStop=4.0))
+    oc = oracle_lib.OracleCamera().update(**p)
+    oc.update(**dict(p, fStop=4.0))
+    assert np.array_equal(bits(pc.info()["lutBoxes"]), bits(oc.lut()[1]))
+    assert not np.array_equal(pc.info()["lutBoxes"], fresh.info()["lutBoxes"])
+
+
+def test_tables_only_camera_cannot_make_rays():
+    cam = ZoicCamera(device=-1).update(**camera_params("C2"))
+    with pytest.raises(ZoicError) as e:
+        cam.create_rays(np.zeros((4, 4), np.float32))
+    assert e.value.status_name == "ZOIC_ERR_NO_DEVICE"
+
+
+def test_bokeh_tie_rule_and_small_images(oracle_lib):
+    """Flat image: every sort key ties; both sides must break ties by ascending index."""
+    for img in (np.ones((4, 6, 3), np.float32), np.tile(np.array([[0, 1, 1, 0]], np.float32)[:, :, None], (3, 1, 3))):
+        pc, oc = ZoicCamera(device=-1), oracle_lib.OracleCamera()
+        pc.set_bokeh_image(img)
+        oc.set_bokeh_image(img)
+        kw = dict(lensModel=THINLENS, useImage=True, bokehPath="mem:flat")
+        pc.update(**kw)
+        oc.update(**kw)
+        a, b = pc.bokeh_tables(), oc.bokeh_tables()
+        for k in ("rowIndices", "columnIndices"):
+            assert np.array_equal(a[k], b[k])
+        for k in ("cdfRow", "cdfColumn"):
+            assert np.array_equal(bits(a[k]), bits(b[k]))
+    # fewer than 3 channels is invalid (isValid, zoic.cpp:135-137)
+    pc = ZoicCamera(device=-1)
+    pc.set_bokeh_image(np.ones((4, 4, 1), np.float32))
+    with pytest.raises(ZoicError):
+        pc.update(lensModel=THINLENS, useImage=True, bokehPath="mem:1ch")

@@ -1,0 +1,67 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard a frame by global ray index, generate their slabs and
+gather them on rank 0; the result must be bit-identical to the unsharded frame.  The ray generator plugged in here is
+the CPU oracle (the checker) -- on GPUs bench.py plugs in ZoicCamera.create_rays; the sharding/gather code is shared."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slabs_partition_the_frame():
+    from zoic_amd.sharding import all_slabs, slab_for_rank
+    for n in (0, 1, 255, 256, 257, 1000, 132710400, 2123366400):
+        for world in (1, 2, 3, 8):
+            slabs = all_slabs(n, world)
+            assert slabs[0][0] == 0 and slabs[-1][1] == n
+            for (a, b), (c, d) in zip(slabs, slabs[1:]):
+                assert b == c and a <= b
+            assert all(a % 256 == 0 for a, _ in slabs)
+            sizes = [b - a for a, b in slabs]
+            assert max(sizes) - min(sizes) <= 256 or n < 256 * world
+    with pytest.raises(ValueError):
+        slab_for_rank(10, 2, 2)
+
+
+def _worker(rank, world, port, n, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from zoic_amd.sharding import gather_planes, slab_for_rank
+    from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = CONFIGS["C2"]
+    lo, hi = slab_for_rank(n, rank, world)
+    oc = oracle.OracleCamera().update(**camera_params("C2"))
+    s = synthetic_samples(hi - lo, c["width"], c["height"], c["spp"], seed=1, ray_index_base=lo)
+    r = oc.create_rays(s, rng_states=ray_rng_states(hi - lo, 1, lo))
+    full, fl = gather_planes(torch.from_numpy(r["planes"].copy()), torch.from_numpy(r["flags"].copy()), n, dist, dst=0)
+    if rank == 0:
+        np.save(os.path.join(outdir, "planes.npy"), full.numpy())
+        np.save(os.path.join(outdir, "flags.npy"), fl.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_equals_single_process(tmp_path, oracle_lib):
+    import torch.multiprocessing as mp
+    from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
+    n = 3000  # not a multiple of the tile: ragged slabs (1536 + 1464)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    c = CONFIGS["C2"]
+    oc = oracle_lib.OracleCamera().update(**camera_params("C2"))
+    ref = oc.create_rays(synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1), rng_states=ray_rng_states(n, 1, 0))
+    got = np.load(tmp_path / "planes.npy")
+    assert np.array_equal(got.view(np.uint32), ref["planes"].view(np.uint32))
+    assert np.array_equal(np.load(tmp_path / "flags.npy"), ref["flags"])
