@@ -7,6 +7,7 @@
 //   zoic_camera_destroy  <- node_finish      zoic.cpp:1723-1749
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,13 +82,15 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     KolbTable kolb{};
     ThinTable thin{};
     // device state
-    DeviceBuffer<float> dCdfRow, dCdfColumn;
+    DeviceBuffer<float> dCdfRow, dCdfColumn, dPyramid;
     DeviceBuffer<int32_t> dRowIdx, dColIdx;
+    BokehTables bokehDev{};
     DeviceCounters *dCounters = nullptr;
     DeviceBuffer<float> dSamples, dPlanes, dInputs7, dProbeU, dProbeV;
     DeviceBuffer<uint32_t> dRng;
     DeviceBuffer<uint8_t> dFlags, dProbeOk;
     unsigned int *dProbeTir = nullptr;
+    unsigned int *dWorkCursor = nullptr;
 };
 
 namespace {
@@ -145,9 +148,46 @@ void lut_trace_device(const KolbTable &table, float originX, const float *lensU,
     *tirCount += tir;
 }
 
+// one padded pyramid: level 0 = the CDF, level j+1 = last element of each 16-chunk of level j (tables.hpp)
+struct Pyramid {
+    int levels = 0;
+    int count[kBokehMaxLevels] = {0, 0, 0}, stride[kBokehMaxLevels] = {0, 0, 0};
+};
+
+Pyramid pyramid_shape(int n)
+{
+    Pyramid p;
+    int cnt = n;
+    for (int j = 0; j < kBokehMaxLevels; ++j) {
+        p.count[j] = cnt;
+        p.stride[j] = (cnt + 15) / 16 * 16;
+        p.levels = j + 1;
+        if (cnt <= 16) return p;
+        cnt = (cnt + 15) / 16;
+    }
+    p.levels = 0;  // more than 16^3 entries: not covered, the kernels binary-search the plain CDF
+    return p;
+}
+
+// append the padded levels of one CDF (n floats) to `dst`; returns per-level offsets
+void pyramid_fill(const float *cdf, const Pyramid &shape, float *const levelBase[kBokehMaxLevels], size_t rowIndex)
+{
+    const float inf = INFINITY;
+    for (int j = 0; j < shape.levels; ++j) {
+        float *dst = levelBase[j] + rowIndex * static_cast<size_t>(shape.stride[j]);
+        const float *src = j == 0 ? cdf : levelBase[j - 1] + rowIndex * static_cast<size_t>(shape.stride[j - 1]);
+        for (int i = 0; i < shape.stride[j]; ++i) {
+            if (i >= shape.count[j]) dst[i] = inf;
+            else if (j == 0) dst[i] = src[i];
+            else dst[i] = src[std::min(16 * i + 15, shape.count[j - 1] - 1)];
+        }
+    }
+}
+
 zoic_status upload_bokeh(zoic_camera *cam)
 {
     const BokehCdf &im = cam->image;
+    cam->bokehDev = BokehTables{};
     if (!im.valid()) return ZOIC_OK;
     const size_t y = static_cast<size_t>(im.y), xy = static_cast<size_t>(im.x) * im.y;
     ZOIC_HIP(cam->dCdfRow.reserve(y));
@@ -158,13 +198,40 @@ zoic_status upload_bokeh(zoic_camera *cam)
     ZOIC_HIP(hipMemcpy(cam->dRowIdx.ptr, im.rowIndices.data(), y * sizeof(int32_t), hipMemcpyHostToDevice));
     ZOIC_HIP(hipMemcpy(cam->dCdfColumn.ptr, im.cdfColumn.data(), xy * sizeof(float), hipMemcpyHostToDevice));
     ZOIC_HIP(hipMemcpy(cam->dColIdx.ptr, im.columnIndices.data(), xy * sizeof(int32_t), hipMemcpyHostToDevice));
+    BokehTables &B = cam->bokehDev;
+    B.cdfRow = cam->dCdfRow.ptr; B.rowIndices = cam->dRowIdx.ptr; B.cdfColumn = cam->dCdfColumn.ptr; B.columnIndices = cam->dColIdx.ptr;
+    // search pyramids (device layout only; same numbers as the reference tables)
+    const Pyramid rp = pyramid_shape(im.y), cp = pyramid_shape(im.x);
+    if (rp.levels == 0 || cp.levels == 0) return ZOIC_OK;
+    const int levels = std::max(rp.levels, cp.levels);  // the kernel walks `levels` levels for both: pad the shorter one
+    Pyramid rshape = rp, cshape = cp;
+    for (int j = 0; j < levels; ++j) {
+        if (j >= rp.levels) { rshape.count[j] = 1; rshape.stride[j] = 16; }
+        if (j >= cp.levels) { cshape.count[j] = 1; cshape.stride[j] = 16; }
+    }
+    rshape.levels = cshape.levels = levels;
+    size_t total = 0, rowOff[kBokehMaxLevels], colOff[kBokehMaxLevels];
+    for (int j = 0; j < levels; ++j) { rowOff[j] = total; total += rshape.stride[j]; }
+    for (int j = 0; j < levels; ++j) { colOff[j] = total; total += static_cast<size_t>(cshape.stride[j]) * y; }
+    std::vector<float> host(total);
+    float *rbase[kBokehMaxLevels] = {nullptr, nullptr, nullptr}, *cbase[kBokehMaxLevels] = {nullptr, nullptr, nullptr};
+    for (int j = 0; j < levels; ++j) { rbase[j] = host.data() + rowOff[j]; cbase[j] = host.data() + colOff[j]; }
+    pyramid_fill(im.cdfRow.data(), rshape, rbase, 0);
+    for (size_t r = 0; r < y; ++r) pyramid_fill(im.cdfColumn.data() + r * im.x, cshape, cbase, r);
+    ZOIC_HIP(cam->dPyramid.reserve(total));
+    ZOIC_HIP(hipMemcpy(cam->dPyramid.ptr, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    for (int j = 0; j < levels; ++j) {
+        B.rowLevel[j] = cam->dPyramid.ptr + rowOff[j];
+        B.colLevel[j] = cam->dPyramid.ptr + colOff[j];
+        B.colStride[j] = cshape.stride[j];
+        B.rowCount[j] = rshape.count[j];
+        B.colCount[j] = cshape.count[j];
+    }
+    B.levels = levels;
     return ZOIC_OK;
 }
 
-BokehTables bokeh_tables(const zoic_camera *cam)
-{
-    return BokehTables{cam->dCdfRow.ptr, cam->dRowIdx.ptr, cam->dCdfColumn.ptr, cam->dColIdx.ptr};
-}
+BokehTables bokeh_tables(const zoic_camera *cam) { return cam->bokehDev; }
 
 void exposure_terms(float exposureControl, float &mul, int32_t &on)  // zoic.cpp:1981-1987
 {
@@ -242,6 +309,7 @@ zoic_status zoic_camera_create(int device, zoic_camera **out)
     cam->lutOnHost = env && env[0] == '1';
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&cam->dCounters), sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipMemset(cam->dCounters, 0, sizeof(DeviceCounters));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), sizeof(unsigned int));
     if (e != hipSuccess) {
         delete cam;
         return fail(ZOIC_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e));
@@ -255,11 +323,12 @@ void zoic_camera_destroy(zoic_camera *cam)
     if (!cam) return;
     if (cam->device == ZOIC_DEVICE_NONE) { delete cam; return; }
     (void)hipSetDevice(cam->device);
-    cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release();
+    cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release();
     cam->dSamples.release(); cam->dPlanes.release(); cam->dInputs7.release(); cam->dRng.release(); cam->dFlags.release();
     cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release();
     if (cam->dProbeTir) (void)hipFree(cam->dProbeTir);
     if (cam->dCounters) (void)hipFree(cam->dCounters);
+    if (cam->dWorkCursor) (void)hipFree(cam->dWorkCursor);
     delete cam;
 }
 
@@ -401,7 +470,7 @@ zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d
     switch (cam->params.p.lensModel) {
     case ZOIC_RAYTRACED:
         rc = launch_kolb_rays(cam->kolb, bokeh_tables(cam), d_samples, d_rng_states, ray_index_base, n, planes, cam->dCounters,
-                              cam->precision == ZOIC_PRECISION_FAST, stream);
+                              cam->dWorkCursor, cam->precision == ZOIC_PRECISION_FAST, stream);
         break;
     case ZOIC_THINLENS:
         rc = launch_thin_rays(cam->thin, bokeh_tables(cam), d_samples, d_rng_states, ray_index_base, n, planes, cam->dCounters, stream);

@@ -1,0 +1,61 @@
+// device_search.hpp -- std::upper_bound on the bokeh CDFs through the 16-ary pyramid of tables.hpp.
+//
+// imageData::bokehSample (zoic.cpp:420-485) does two std::upper_bound binary searches per lens sample: 8 + 8
+// dependent loads for a 256x256 image, each a different cache line per lane.  On the device one pyramid level is
+// one aligned 64-byte line fetched with four global_load_dwordx4 (a single round trip); the position inside the line
+// is the COUNT of entries <= u (the array is non-decreasing, so that count is the upper_bound index).  Padding is
+// +inf, the result is clamped to n, which makes the index identical to std::upper_bound for every u including
+// NaN (count saturates -> n) -- so strict mode stays bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "optics.hpp"
+#include "tables.hpp"
+
+namespace zoic {
+
+__device__ __forceinline__ int chunk_count_le(const float *chunk, float v)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(chunk);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    int n = 0;
+    n += !(v < a.x); n += !(v < a.y); n += !(v < a.z); n += !(v < a.w);
+    n += !(v < b.x); n += !(v < b.y); n += !(v < b.z); n += !(v < b.w);
+    n += !(v < c.x); n += !(v < c.y); n += !(v < c.z); n += !(v < c.w);
+    n += !(v < d.x); n += !(v < d.y); n += !(v < d.z); n += !(v < d.w);
+    return n;
+}
+
+// upper_bound over one CDF given its pyramid levels; `row` selects the padded row at each level (0 for the row CDF)
+__device__ __forceinline__ int pyramid_upper_bound(const float *const level[kBokehMaxLevels], const int32_t stride[kBokehMaxLevels],
+                                                   const int32_t count[kBokehMaxLevels], int levels, int row, float v)
+{
+    int pos = 0;
+#pragma unroll
+    for (int j = kBokehMaxLevels - 1; j >= 0; --j) {
+        if (j >= levels) continue;
+        const float *chunk = level[j] + static_cast<size_t>(row) * stride[j] + static_cast<size_t>(pos) * 16;
+        pos = pos * 16 + chunk_count_le(chunk, v);
+        if (pos >= count[j]) return count[0];
+    }
+    return pos;
+}
+
+__device__ __forceinline__ V2 bokeh_sample_device(const BokehTables &B, int x, int y, float uRow, float uCol)
+{
+    if (B.levels == 0)  // CDF longer than the pyramid covers: the reference's binary search
+        return bokeh_sample(B.cdfRow, B.rowIndices, B.cdfColumn, B.columnIndices, x, y, uRow, uCol);
+    const int32_t zeroStride[kBokehMaxLevels] = {0, 0, 0};
+    int r = pyramid_upper_bound(B.rowLevel, zeroStride, B.rowCount, B.levels, 0, uRow);
+    if (r >= y) r = y - 1;
+    const int row = B.rowIndices[r];
+    int c = pyramid_upper_bound(B.colLevel, B.colStride, B.colCount, B.levels, row, uCol);
+    if (c >= x) c = x - 1;
+    const int start = row * x;
+    const int col = B.columnIndices[start + c] - start;
+    const float flippedRow = static_cast<float>(col - ((y - 1) / 2));             // zoic.cpp:466,479 (x/y swapped)
+    const float flippedColumn = static_cast<float>(row - ((x - 1) / 2)) * -1.0f;  // zoic.cpp:441,480
+    return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
+}
+
+}  // namespace zoic

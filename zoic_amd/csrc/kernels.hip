@@ -12,6 +12,10 @@
 // against the CPU oracle.  The FAST variant lives in kolb_fast.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
+#include "device_search.hpp"
 #include "kernels.hpp"
 #include "optics.hpp"
 
@@ -56,7 +60,7 @@ __device__ __forceinline__ void flush_counters(DeviceCounters *c, uint32_t succ,
 
 __device__ __forceinline__ V2 sample_lens(bool useImage, const BokehTables &B, int bw, int bh, float u, float v)
 {
-    if (useImage) return bokeh_sample(B.cdfRow, B.rowIndices, B.cdfColumn, B.columnIndices, bw, bh, u, v);
+    if (useImage) return bokeh_sample_device(B, bw, bh, u, v);
     return concentric_disk(u, v);
 }
 
@@ -236,11 +240,23 @@ static inline unsigned grid_for(uint64_t n)
 
 int launch_kolb_fast(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                      uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream);
+int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                       uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                       bool fast, void *stream);
+
+// ZOIC_KOLB_VARIANT=simple selects the one-sample-per-lane kernels (A/B baseline); default: persistent lane refill
+static bool use_simple_variant()
+{
+    const char *e = std::getenv("ZOIC_KOLB_VARIANT");
+    return e && std::strcmp(e, "simple") == 0;
+}
 
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, bool fast, void *stream)
+                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                     bool fast, void *stream)
 {
     if (n == 0) return 0;
+    if (!use_simple_variant()) return launch_kolb_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, fast, stream);
     if (fast) return launch_kolb_fast(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, stream);
     hipLaunchKernelGGL(kolb_rays_strict_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,
                        reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,

@@ -17,8 +17,10 @@ struct DeviceCounters {  // zoic.cpp:533-534: succesRays, vignettedRays, totalIn
 };
 
 // camera_create_ray, RAYTRACED branch (zoic.cpp:1850-1964) over n samples.  fast=false: strict arithmetic.
+// d_workCursor: one device word the persistent kernel uses as its chunk cursor (zeroed on the stream per launch).
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, bool fast, void *stream);
+                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                     bool fast, void *stream);
 
 // camera_create_ray, THINLENS branch (zoic.cpp:1771-1846)
 int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,

@@ -1,4 +1,6 @@
-// kolb_fast.hip -- FAST-mode Kolb kernel for gfx950: the same algorithm as the strict kernel (kernels.hip,
+// kolb_fast.hip -- the SIMPLE fast-mode kernel (one sample per lane, retry loop inside the lane).  Kept as the
+// A/B baseline of the optimisation ladder in DESIGN.md (ZOIC_KOLB_VARIANT=simple); production is kolb_refill.hip.
+// FAST-mode arithmetic (fast_optics.hpp): the same algorithm as the strict kernel (kernels.hip,
 // zoic.cpp:1850-1964) with the arithmetic re-associated for the VALU:
 //   * f32 only (the reference's f64 intermediates dropped), FMA contraction on;
 //   * the ray direction is normalised once (v_rsq_f32) and then kept unit by construction -- the reference
@@ -9,6 +11,8 @@
 // decides (measured by tests/test_parity_gpu.py: direction RMSE < 1e-5, flip fraction reported).
 #include <hip/hip_runtime.h>
 
+#include "device_search.hpp"
+#include "fast_optics.hpp"
 #include "kernels.hpp"
 #include "optics.hpp"
 
@@ -18,58 +22,10 @@ namespace zoic {
 
 constexpr int kBlockF = 256;
 
-__device__ __forceinline__ float fsqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float frsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
-
-__device__ __forceinline__ float fast_sin_f32(float x) { return parabola_sin(wrap_to_pi(x)); }
-__device__ __forceinline__ float fast_cos_f32(float x) { return parabola_sin(wrap_to_pi(x + kPiOver2)); }
-
-__device__ __forceinline__ V2 concentric_disk_f32(float ox, float oy)
-{
-    const float a = 2.0f * ox - 1.0f, b = 2.0f * oy - 1.0f;
-    float r, phi;
-    if ((a * a) > (b * b)) { r = a; phi = 0.78539816339f * (b / a); }
-    else { r = b; phi = kPiOver2 - 0.78539816339f * (a / b); }
-    return V2{r * fast_cos_f32(phi), r * fast_sin_f32(phi)};
-}
-
 __device__ __forceinline__ V2 sample_lens_f32(bool useImage, const BokehTables &B, int bw, int bh, float u, float v)
 {
-    if (useImage) return bokeh_sample(B.cdfRow, B.rowIndices, B.cdfColumn, B.columnIndices, bw, bh, u, v);
+    if (useImage) return bokeh_sample_device(B, bw, bh, u, v);
     return concentric_disk_f32(u, v);
-}
-
-// d is the raw (unnormalised) direction on entry; it is replaced by the refracted unit direction at the first
-// surface, and left untouched if the ray dies before that -- the same partial state the reference leaves.
-__device__ __forceinline__ bool trace_lens_fast(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
-{
-    const int n = T.lensCount;
-    V3 u = d;
-    {
-        const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
-        u = V3{d.x * inv, d.y * inv, d.z * inv};
-    }
-    for (int i = 0; i < n; ++i) {
-        const Surface S = T.surf[i];
-        const float Lx = -o.x, Ly = -o.y, Lz = S.center - o.z;
-        const float tca = Lx * u.x + Ly * u.y + Lz * u.z;
-        const float d2 = (Lx * Lx + Ly * Ly + Lz * Lz) - tca * tca;
-        if (d2 > S.radius2) return false;
-        const float thc = fsqrt_fast(fabsf(S.radius2 - d2));
-        const float t = tca + thc * S.sign;
-        const V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
-        const float h2 = hit.x * hit.x + hit.y * hit.y;
-        if (h2 > S.housing2 || (i == T.apertureElement && h2 > T.userAperture2)) return false;
-        const V3 N{-hit.x * S.invRadius, -hit.y * S.invRadius, (S.center - hit.z) * S.invRadius};
-        o = hit;
-        const float c1 = -(u.x * N.x + u.y * N.y + u.z * N.z);
-        const float cs2 = (S.eta * S.eta) * (1.0f - c1 * c1);
-        if (S.tirPossible && cs2 > 1.0f) { ++tirCount; return false; }
-        const float k = S.eta * c1 - fsqrt_fast(fabsf(1.0f - cs2));
-        u = V3{u.x * S.eta + N.x * k, u.y * S.eta + N.y * k, u.z * S.eta + N.z * k};
-        d = u;
-    }
-    return true;
 }
 
 __global__ __launch_bounds__(kBlockF) void kolb_rays_fast_kernel(const KolbTable T, const BokehTables B,

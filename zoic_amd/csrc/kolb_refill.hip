@@ -1,0 +1,215 @@
+// kolb_refill.hip -- the production Kolb kernel: persistent waves with ballot/prefix-sum lane refill.
+//
+// Why.  camera_create_ray retries a rejected sample up to 26 more times (zoic.cpp:1927-1947).  With one sample per
+// lane and the retry loop inside the lane, a wave keeps iterating until its unluckiest lane is done: rocprof on the
+// first kernel (profiles/r01_fast_v0) showed ~25 % VALU lane utilisation and 6000 lane-instructions per ray for a
+// ~900-instruction first try.  Here a wave is persistent instead: every pass of the loop runs exactly ONE try for each
+// of its 64 lanes; lanes whose ray finished (accepted, or out of tries) are refilled from the wave's sample cursor
+// before the next pass:
+//     freeMask = ballot(!active)             -- which lanes need work
+//     rank     = mbcnt(freeMask)             -- exclusive prefix sum: my slot among the free lanes
+//     mine     = cursor + rank               -- consecutive samples go to the free lanes (loads stay contiguous)
+//     cursor  += popcount(freeMask)          -- wave-uniform, lives in an SGPR; no atomics, no LDS, no barriers
+// so vignetted rays never hold finished lanes hostage, whatever the reject rate.  The cursor walks a 1024-sample
+// chunk claimed with one atomicAdd on a global work cursor: waves that drew cheap image regions simply claim more
+// chunks, so the frame's heavily vignetted corners cannot unbalance the chip and the grid size need not match the
+// true residency.  Retry streams are per ray (keyed by the global ray index), hence the result of every ray is
+// independent of which lane/pass/wave evaluated it -- the strict instantiation is bit-identical to the simple
+// one-sample-per-lane kernel and to the CPU oracle.
+//
+// Tables: the lens prescription + LUT arrive by value (SGPRs via s_load, see tables.hpp); bokeh CDFs are searched
+// through the 16-ary pyramid (device_search.hpp).  Samples: one global_load_dwordx4 per refilled lane.  Rays: seven
+// 4-byte planes + a flag byte, written by the lanes that finished in this pass (their indices are consecutive within
+// a 64-sample window, so the stores land in a handful of cache lines).
+#include <hip/hip_runtime.h>
+
+#include "device_search.hpp"
+#include "fast_optics.hpp"
+#include "kernels.hpp"
+#include "optics.hpp"
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace zoic {
+
+constexpr int kRefillBlock = 256;
+constexpr int kWavesPerBlock = kRefillBlock / 64;
+constexpr uint32_t kChunkRays = 1024;  // samples a wave claims per atomic on the work cursor (16 passes of fresh work)
+
+template <bool STRICT>
+__device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, float u, float v)
+{
+    if (T.useImage) return bokeh_sample_device(B, T.bokehW, T.bokehH, u, v);
+    if constexpr (STRICT) return concentric_disk(u, v);
+    else return concentric_disk_f32(u, v);
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTable T, const BokehTables B,
+                                                                   const float4 *__restrict__ samples,
+                                                                   const uint4 *__restrict__ rngStates, uint64_t rayBase,
+                                                                   uint32_t n, const RayPlanes out, DeviceCounters *counters,
+                                                                   unsigned int *__restrict__ workCursor)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    // wave-uniform work window [next, end): a chunk of kChunkRays consecutive samples claimed from the global cursor
+    uint32_t next = 0, end = 0;
+    bool exhausted = false;
+
+    // per-lane ray state, alive across passes
+    bool active = false, fresh = false, dead = false;
+    uint32_t idx = 0, tries = 0, lutMiss = 0;
+    float o0x = 0, o0y = 0, maxScale = 0, translation = 0, sn = 0, cs = 1, u = 0, v = 0;
+    Rng rng{1, 2, 3, 4};
+    uint32_t succ = 0, vign = 0, tir = 0;
+
+    for (;;) {
+        // ---- refill the free lanes from the work window (ballot + prefix sum) ---------------------------------
+        unsigned long long freeMask = __ballot(!active);
+        while (freeMask != 0ull && !exhausted) {
+            if (next >= end) {  // claim the next chunk: one atomic per kChunkRays samples per wave
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(workCursor, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                const uint64_t begin = static_cast<uint64_t>(c) * kChunkRays;
+                if (begin >= n) { exhausted = true; break; }
+                next = static_cast<uint32_t>(begin);
+                end = (begin + kChunkRays < n) ? static_cast<uint32_t>(begin + kChunkRays) : n;
+            }
+            const uint32_t avail = end - next;
+            const uint32_t nfree = static_cast<uint32_t>(__popcll(freeMask));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(freeMask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(freeMask), 0u));
+            if (!active && rank < avail) {
+                idx = next + rank;
+                const float4 s = samples[idx];  // (sx, sy, lensx, lensy)
+                if (rngStates) { const uint4 r = rngStates[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+                else rng = rng_for_ray(T.seed, rayBase + idx);
+                o0x = s.x * T.halfSensor;  // zoic.cpp:1853-1854
+                o0y = s.y * T.halfSensor;
+                u = s.z; v = s.w;
+                tries = 0; lutMiss = 0; dead = false;
+                if (T.useLUT) {            // zoic.cpp:1891-1911: per-sample constants of the exit-pupil transform
+                    if constexpr (STRICT) {
+                        const float dist = fabsf(sqrtf(o0x * o0x + o0y * o0y));
+                        const float theta = static_cast<float>(atan2(static_cast<double>(o0y), static_cast<double>(o0x)));
+                        sn = fast_sin(theta);
+                        cs = fast_cos(theta);
+                        lutMiss = lut_lookup(T, dist, maxScale, translation) ? 0u : 1u;
+                    } else {
+                        const float dist = fsqrt_fast(o0x * o0x + o0y * o0y);
+                        const float theta = atan2f(o0y, o0x);
+                        sn = fast_sin_f32(theta);
+                        cs = fast_cos_f32(theta);
+                        lutMiss = lut_lookup(T, dist, maxScale, translation) ? 0u : 1u;
+                    }
+                    // Outside the image circle the LUT entries are all zero (zoic.cpp:1403-1404 never grown): every try
+                    // then shoots lens = (0,0).  With o0x != 0 and o0y != 0 the direction (0 - o0x, 0 - o0y, dirZ) is
+                    // bit-identical for all 27 tries whatever the signs of the zeros, so one failed trace decides them all.
+                    dead = (maxScale == 0.0f) && (translation == 0.0f) && (o0x != 0.0f) && (o0y != 0.0f);
+                }
+                active = true; fresh = true;
+            }
+            next += (nfree < avail) ? nfree : avail;
+            if (nfree <= avail) break;
+            freeMask = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+
+        // ---- one try for every active lane ---------------------------------------------------------------------
+        if (active) {
+            if (!fresh) {                       // retry: new lens sample from the ray's own stream, zoic.cpp:1930
+                u = rng_unit(xor128(rng));
+                v = rng_unit(xor128(rng));
+                ++tries;
+            }
+            V2 lens = lens_sample<STRICT>(T, B, u, v);
+            // the dead-pixel shortcut needs a finite first sample (NaN*0 would differ from later tries)
+            const bool finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
+            V3 o{o0x, o0y, T.originShift}, d;
+            if (!T.useLUT) {                    // zoic.cpp:1873-1877 / 1882-1884
+                d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+            } else {                            // zoic.cpp:1913-1924 / 1932-1943
+                lens.x *= maxScale; lens.y *= maxScale;
+                lens.x += translation;
+                if (!fresh) lens.y += translation;  // retries translate BOTH components (zoic.cpp:1933)
+                const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
+                d = V3{rx - o.x, ry - o.y, T.dirZ};
+            }
+            const uint32_t tirBefore = tir;
+            bool ok;
+            if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
+            else ok = trace_lens_fast(T, o, d, tir);
+            if (!ok && fresh && dead && finiteSample) {
+                // 26 more identical failures: account for their TIR bumps, then finish the ray as the reference would
+                tir += (tir - tirBefore) * (static_cast<uint32_t>(kMaxTries) + 1u);
+                tries = static_cast<uint32_t>(kMaxTries) + 1u;
+            }
+            fresh = false;
+            if (ok || tries > static_cast<uint32_t>(kMaxTries)) {  // loop exit of zoic.cpp:1927
+                float w = 1.0f;
+                if (tries > static_cast<uint32_t>(kMaxTries)) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
+                if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
+                if (out.ox) out.ox[idx] = o.x * -1.0f;   // zoic.cpp:1960-1961
+                if (out.oy) out.oy[idx] = o.y * -1.0f;
+                if (out.oz) out.oz[idx] = o.z * -1.0f;
+                if (out.dx) out.dx[idx] = d.x * -1.0f;
+                if (out.dy) out.dy[idx] = d.y * -1.0f;
+                if (out.dz) out.dz[idx] = d.z * -1.0f;
+                if (out.weight) out.weight[idx] = w;
+                if (out.flags) out.flags[idx] = static_cast<uint8_t>((tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6));
+                active = false;
+            }
+        }
+    }
+
+    // ---- counters: wave reduction, one atomic per counter per wave ---------------------------------------------
+    if (counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            succ += __shfl_down(succ, off, 64);
+            vign += __shfl_down(vign, off, 64);
+            tir += __shfl_down(tir, off, 64);
+        }
+        if (lane == 0) {
+            if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
+            if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
+            if (tir) atomicAdd(&counters->tir, static_cast<unsigned long long>(tir));
+        }
+    }
+}
+
+int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                       uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                       bool fast, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // one launch covers < 2^31 samples (32-bit ray offsets inside the kernel); larger batches are split
+    constexpr uint64_t kMaxPerLaunch = 1ull << 31;
+    for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
+        const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
+        hipError_t e = hipMemsetAsync(d_workCursor, 0, sizeof(unsigned int), st);
+        if (e != hipSuccess) return static_cast<int>(e);
+        // persistent waves: enough workgroups to fill every wave slot of 256 CUs (8 x 256 lanes per CU); late or
+        // surplus workgroups find the cursor exhausted and retire at once, so residency need not be known exactly
+        const uint64_t chunks = (m + kChunkRays - 1) / kChunkRays;
+        const uint64_t wantBlocks = (chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+        const unsigned grid = static_cast<unsigned>(wantBlocks < 2048 ? (wantBlocks ? wantBlocks : 1) : 2048);
+        RayPlanes o = out;
+        if (o.ox) o.ox += done; if (o.oy) o.oy += done; if (o.oz) o.oz += done;
+        if (o.dx) o.dx += done; if (o.dy) o.dy += done; if (o.dz) o.dz += done;
+        if (o.weight) o.weight += done; if (o.flags) o.flags += done;
+        const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
+        const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
+        if (fast)
+            hipLaunchKernelGGL(kolb_refill_kernel<false>, dim3(grid), dim3(kRefillBlock), 0, st, table, bokeh, sp, rp, rayBase + done,
+                               static_cast<uint32_t>(m), o, d_counters, d_workCursor);
+        else
+            hipLaunchKernelGGL(kolb_refill_kernel<true>, dim3(grid), dim3(kRefillBlock), 0, st, table, bokeh, sp, rp, rayBase + done,
+                               static_cast<uint32_t>(m), o, d_counters, d_workCursor);
+        e = hipGetLastError();
+        if (e != hipSuccess) return static_cast<int>(e);
+    }
+    return 0;
+}
+
+}  // namespace zoic

@@ -67,12 +67,23 @@ struct ThinTable {
     uint32_t seed;
 };
 
-// device pointers of the bokeh CDF tables (bokehProbability, zoic.cpp:222-417)
+// device pointers of the bokeh CDF tables (bokehProbability, zoic.cpp:222-417).
+// Besides the reference's four arrays the device keeps a 16-ary search pyramid over each CDF: level 0 is the CDF
+// itself, level j+1 holds the LAST element of every 16-element chunk of level j, every level padded with +inf to a
+// multiple of 16 floats so that one chunk is one aligned 64-byte line (4 x global_load_dwordx4, one round trip).
+// std::upper_bound over 256 entries then costs 2 dependent loads instead of 8 (device_search.hpp).
+constexpr int kBokehMaxLevels = 3;  // 16^3 = 4096 entries per CDF; larger images use the plain binary search
 struct BokehTables {
-    const float *cdfRow;          // y
+    const float *cdfRow;          // y            (unpadded, reference layout)
     const int32_t *rowIndices;    // y
-    const float *cdfColumn;       // x*y
+    const float *cdfColumn;       // x*y          (unpadded, reference layout)
     const int32_t *columnIndices; // x*y
+    const float *rowLevel[kBokehMaxLevels];  // padded pyramid of cdfRow
+    const float *colLevel[kBokehMaxLevels];  // padded pyramid of cdfColumn, one padded row per image row
+    int32_t colStride[kBokehMaxLevels];      // floats per image row at each level (multiple of 16)
+    int32_t rowCount[kBokehMaxLevels];       // valid entries per level of the row pyramid
+    int32_t colCount[kBokehMaxLevels];       // valid entries per level of one column pyramid row
+    int32_t levels;                          // 0: pyramid not built (CDF longer than 4096) -> binary search
 };
 
 }  // namespace zoic
