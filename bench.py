@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_RAY = 44  # 16 B sample in + 28 B (origin, dir, weight) out; SURVEY 8(d).  The flag byte is extra.
+ALGO_BYTES_PER_RAY = 48  # 16 B sample in + one 32 B ray record out (28 B origin/dir/weight of SURVEY 8(d) + the 4 B flag word)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3
 
@@ -121,7 +121,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from zoic_amd.sharding import gather_planes, slab_for_rank
+    from zoic_amd.sharding import gather_rays, slab_for_rank
     cfg = CONFIGS[args.config]
     frame = args.rays or ray_count(args.config)
     if args.scaling == "strong":
@@ -137,11 +137,11 @@ def main():
 
     # inputs resident in HBM before the timed region
     samples = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=base)
-    out = dict(planes=torch.empty((7, n), dtype=torch.float32, device=dev), flags=torch.empty(n, dtype=torch.uint8, device=dev))
+    out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device=dev))
     def step():
         cam.create_rays(samples, ray_index_base=base, out=out)
         if args.gather and world > 1:
-            gather_planes(out["planes"], out["flags"], n_total, dist, dst=0)
+            gather_rays(out["rays"], n_total, dist, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -156,7 +156,7 @@ def main():
         cam.create_rays(samples, ray_index_base=base, out=out)
         ev[k][1].record()
         if args.gather and world > 1:
-            gather_planes(out["planes"], out["flags"], n_total, dist, dst=0)
+            gather_rays(out["rays"], n_total, dist, dst=0)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -192,7 +192,7 @@ def main():
                        "gather": bool(args.gather and world > 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "kolb_rays_%s_kernel" % args.precision if cfg["params"]["lensModel"] == 1 else "thin_rays_kernel",
+                         "kernel": ("kolb_refill_kernel<%s>" % ("false" if args.precision == "fast" else "true")) if cfg["params"]["lensModel"] == 1 else "thin_rays_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_ray": ALGO_BYTES_PER_RAY,
                          "note": "Kolb path is FP32-VALU bound (DESIGN.md); HBM fraction reported per the bench contract"},
             "zero_weight_frac": round(counters["vignettedRays"] / max(done, 1), 5),

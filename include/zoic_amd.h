@@ -82,15 +82,15 @@ typedef struct zoic_camera_output {
     float weight[3];
 } zoic_camera_output;
 
-/* Batch output, structure of arrays: 7 planes of n floats + 1 flag byte per ray.
+/* Batch output: one 32-byte record per ray (the fields of AtCameraOutput that zoic writes, zoic.cpp:1752-1990).
  * flags: bit0 = retried (tries > 0  => the caller sets dOdy=origin, dDdy=dir, zoic.cpp:1974-1977),
  *        bits1-5 = tries (0..26; 26 => weight 0, zoic.cpp:1951-1953), bit6 = outside the exit-pupil LUT (fenced UB). */
-typedef struct zoic_ray_planes {
-    float *ox, *oy, *oz;
-    float *dx, *dy, *dz;
-    float *weight;
-    uint8_t *flags;
-} zoic_ray_planes;
+typedef struct zoic_ray {
+    float ox, oy, oz;   /* output.origin */
+    float dx, dy, dz;   /* output.dir    */
+    float weight;       /* output.weight (r == g == b; the caller's initial weight is taken as 1) */
+    uint32_t flags;
+} zoic_ray;
 
 /* struct cameraData (zoic.cpp:627-643) + its device tables */
 typedef struct zoic_camera zoic_camera;
@@ -128,15 +128,15 @@ zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed);
  *   d_rng_states : NULL, or n x 4 u32 xorshift128 states (zoic.cpp:647-652), one private retry stream per ray.
  *                  NULL => ray i uses the stream seeded from (seed, ray_index_base + i), so results do not
  *                  depend on how the image is split over launches or GPUs.
- *   out          : device pointers; any plane may be NULL (not written)
+ *   d_rays       : n zoic_ray records in device memory, 16-byte aligned
  *   stream       : hipStream_t (NULL = default stream).  Asynchronous.
  * The reference draws retries from ONE process-global stream shared (racily) by all render threads
  * (zoic.cpp:648); a per-ray stream is the only order-independent restatement. */
 zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng_states,
-                                    uint64_t ray_index_base, zoic_ray_planes out, void *stream);
+                                    uint64_t ray_index_base, zoic_ray *d_rays, void *stream);
 /* same, host buffers: H2D, kernels, D2H, synchronous */
 zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_samples, const uint32_t *h_rng_states,
-                                  uint64_t ray_index_base, zoic_ray_planes out);
+                                  uint64_t ray_index_base, zoic_ray *h_rays);
 /* Arnold-layout batch: n AtCameraInput -> n AtCameraOutput (host).  outputs must arrive initialised the way
  * Arnold hands them to camera_create_ray (origin 0, weight 1; thin-lens reads output.origin, zoic.cpp:1777). */
 zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_camera_input *inputs,

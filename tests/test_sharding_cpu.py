@@ -31,7 +31,7 @@ def _worker(rank, world, port, n, outdir):
     import torch
     import torch.distributed as dist
     import oracle
-    from zoic_amd.sharding import gather_planes, slab_for_rank
+    from zoic_amd.sharding import gather_rays, slab_for_rank
     from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,10 +41,12 @@ def _worker(rank, world, port, n, outdir):
     oc = oracle.OracleCamera().update(**camera_params("C2"))
     s = synthetic_samples(hi - lo, c["width"], c["height"], c["spp"], seed=1, ray_index_base=lo)
     r = oc.create_rays(s, rng_states=ray_rng_states(hi - lo, 1, lo))
-    full, fl = gather_planes(torch.from_numpy(r["planes"].copy()), torch.from_numpy(r["flags"].copy()), n, dist, dst=0)
+    rec = np.zeros((hi - lo, 8), np.float32)          # the (n,8) zoic_ray record layout the GPU path produces
+    rec[:, :7] = r["planes"].T
+    rec[:, 7] = r["flags"].astype(np.uint32).view(np.float32)
+    full = gather_rays(torch.from_numpy(rec), n, dist, dst=0)
     if rank == 0:
-        np.save(os.path.join(outdir, "planes.npy"), full.numpy())
-        np.save(os.path.join(outdir, "flags.npy"), fl.numpy())
+        np.save(os.path.join(outdir, "rays.npy"), full.numpy())
     else:
         assert full is None
     dist.barrier()
@@ -62,6 +64,7 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path, oracle_lib):
     c = CONFIGS["C2"]
     oc = oracle_lib.OracleCamera().update(**camera_params("C2"))
     ref = oc.create_rays(synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1), rng_states=ray_rng_states(n, 1, 0))
-    got = np.load(tmp_path / "planes.npy")
-    assert np.array_equal(got.view(np.uint32), ref["planes"].view(np.uint32))
-    assert np.array_equal(np.load(tmp_path / "flags.npy"), ref["flags"])
+    got = np.load(tmp_path / "rays.npy")
+    assert got.shape == (n, 8)
+    assert np.array_equal(np.ascontiguousarray(got[:, :7].T).view(np.uint32), ref["planes"].view(np.uint32))
+    assert np.array_equal(np.ascontiguousarray(got[:, 7]).view(np.uint32), ref["flags"].astype(np.uint32))

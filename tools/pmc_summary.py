@@ -1,0 +1,43 @@
+"""Summarise a tools/profile.sh output directory: kernel stats + PMC-derived rates for the dominant kernel."""
+import collections, csv, glob, json, sys
+base, nrays = sys.argv[1], float(sys.argv[2])
+pat = sys.argv[3] if len(sys.argv) > 3 else "kolb"
+st = glob.glob(base + "/trace/*/*_kernel_stats.csv")
+if st:
+    for r in list(csv.DictReader(open(st[0])))[:3]:
+        print("%-60s calls %s avg_us %.1f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+tot = {}
+for d in sorted(glob.glob(base + "/pmc*/*/*_counter_collection.csv")):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(d)):
+        if pat in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            tot["_vgpr"], tot["_sgpr"], tot["_lds"] = r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size")
+    for k, v in acc.items():
+        tot[k] = sum(v) / len(v)
+g = lambda k: tot.get(k, float("nan"))
+cyc = g("GRBM_GUI_ACTIVE") / 8
+simd = cyc * 1024
+out = {
+    "vgpr/sgpr/lds": (tot.get("_vgpr"), tot.get("_sgpr"), tot.get("_lds")),
+    "lane_instr_per_ray": g("SQ_INSTS_VALU") * 64 / nrays,
+    "valu_thread_util": g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64),
+    "salu_per_valu": g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"),
+    "wave_cycles_wait_any": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
+    "wave_cycles_wait_inst": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+    "wave_cycles_active": g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"),
+    "avg_waves_per_simd": g("SQ_WAVE_CYCLES") * 4 / simd,
+    "valu_issue_frac_2cyc": g("SQ_INSTS_VALU") * 2 / simd,
+    "valu_busy_quadcycles": g("SQ_ACTIVE_INST_VALU") * 4 / simd,
+    "vmem_rd_per_ray": g("SQ_INSTS_VMEM_RD") * 64 / nrays, "vmem_wr_per_ray": g("SQ_INSTS_VMEM_WR") * 64 / nrays,
+    "smem_per_wave_instr": g("SQ_INSTS_SMEM") / g("SQ_INSTS_VALU"),
+    "lds_instr_per_ray": g("SQ_INSTS_LDS") * 64 / nrays,
+    "trans_per_ray": g("SQ_INSTS_VALU_TRANS") * 64 / nrays,
+    "hbm_bytes_per_launch": (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024,
+    "fetch_bytes(x2 corrected)": 2 * g("FETCH_SIZE") * 1024, "write_bytes": g("WRITE_SIZE") * 1024,
+    "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
+    "gpu_ms(cycles/2.4GHz)": cyc / 2.4e6,
+}
+for k, v in out.items():
+    print("%-28s %s" % (k, ("%.4g" % v) if isinstance(v, float) else v))
+json.dump({k: v for k, v in out.items()}, open(base + "/summary.json", "w"), indent=1, default=str)

@@ -40,8 +40,12 @@ class CameraOutput(C.Structure):
                 ("weight", C.c_float * 3)]
 
 
-class RayPlanes(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ox", "oy", "oz", "dx", "dy", "dz", "weight", "flags")]
+class Ray(C.Structure):   # zoic_ray: one 32-byte record per camera ray
+    _fields_ = [(n, C.c_float) for n in ("ox", "oy", "oz", "dx", "dy", "dz", "weight")] + [("flags", C.c_uint32)]
+
+
+RAY_DTYPE = [("ox", "<f4"), ("oy", "<f4"), ("oz", "<f4"), ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"), ("weight", "<f4"),
+             ("flags", "<u4")]
 
 
 class Counters(C.Structure):
@@ -74,8 +78,8 @@ SYMBOLS = {
     "zoic_camera_set_lens_text": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "zoic_camera_set_precision": (C.c_int, [_vp, C.c_int]),
     "zoic_camera_set_seed": (C.c_int, [_vp, _u32]),
-    "zoic_create_rays_device": (C.c_int, [_vp, _u64, _vp, _vp, _u64, RayPlanes, _vp]),
-    "zoic_create_rays_host": (C.c_int, [_vp, _u64, _vp, _vp, _u64, RayPlanes]),
+    "zoic_create_rays_device": (C.c_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
+    "zoic_create_rays_host": (C.c_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     "zoic_create_rays_arnold": (C.c_int, [_vp, _u64, C.POINTER(CameraInput), C.POINTER(CameraOutput), _u64]),
     "zoic_camera_create_ray": (C.c_int, [_vp, C.POINTER(CameraInput), C.POINTER(CameraOutput), C.c_uint16]),
     "zoic_generate_samples_device": (C.c_int, [_vp, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _vp]),

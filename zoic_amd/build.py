@@ -15,12 +15,13 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzoic_amd.so")
 SOURCES = ["capi.cpp", "lens_system.cpp", "kernels.hip", "kolb_fast.hip", "kolb_refill.hip"]
-HEADERS = ["tables.hpp", "optics.hpp", "fast_optics.hpp", "device_search.hpp", "lens_system.hpp", "kernels.hpp", os.path.join(ROOT, "include", "zoic_amd.h")]
+HEADERS = ["tables.hpp", "optics.hpp", "fast_optics.hpp", "device_search.hpp", "ray_store.hpp", "lens_system.hpp", "kernels.hpp", os.path.join(ROOT, "include", "zoic_amd.h")]
 
 # -ffp-contract=off: strict kernels and the host precompute must round exactly like the CPU oracle;
-# the fast kernel re-enables contraction locally with a pragma.
+# the fast kernel re-enables contraction locally with a pragma.  -fno-slp-vectorize: packing scalar f32 math into
+# v_pk_* costs more in register shuffles than it saves on gfx950 (measured +8..20 % Mrays/s without it).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
 
 
 def _hipcc():
@@ -41,6 +42,7 @@ def needs_build():
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
+    extra_flags = list(extra_flags) + os.environ.get("ZOIC_EXTRA_HIPCC_FLAGS", "").split()
     cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -52,6 +52,14 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def rays_to_dict(rays):
+    """(n,) zoic_ray records -> convenience views (planes are copies: ox oy oz dx dy dz weight)."""
+    planes = np.stack([rays[k] for k in ("ox", "oy", "oz", "dx", "dy", "dz", "weight")]).astype(np.float32, copy=False)
+    flags = rays["flags"].astype(np.uint8)
+    return dict(rays=rays, planes=planes, origin=planes[0:3], dir=planes[3:6], weight=planes[6], flags=flags,
+                tries=((flags >> 1) & 31).astype(np.int32))
+
+
 class ZoicCamera:
     def __init__(self, device=0):
         self._lib = _capi.load()
@@ -131,9 +139,10 @@ class ZoicCamera:
     def create_rays(self, samples, rng_states=None, ray_index_base=0, out=None, stream=None):
         """samples: (n,4) float32 rows (sx, sy, lensx, lensy).
 
-        numpy in -> dict of numpy planes (host API: H2D, kernels, D2H).
-        torch device tensor in -> dict of torch tensors on the same device (device API, asynchronous on `stream`
-        or torch's current stream).
+        numpy in  -> host API (H2D, kernels, D2H); returns a dict of numpy arrays built from the (n,) zoic_ray records:
+                     rays (structured), planes (7,n) = ox oy oz dx dy dz weight, origin (3,n), dir (3,n), weight, flags, tries.
+        torch device tensor in -> device API, asynchronous on `stream` (default: torch's current stream); returns a dict
+                     with rays = (n,8) float32 tensor (column 7 holds the flag word's bits) and strided views into it.
         """
         if _is_torch(samples):
             return self._create_rays_torch(samples, rng_states, ray_index_base, out, stream)
@@ -141,18 +150,15 @@ class ZoicCamera:
         if s.ndim != 2 or s.shape[1] != 4:
             raise ValueError("samples must be (n, 4)")
         n = s.shape[0]
-        planes = np.empty((7, n), dtype=np.float32)
-        flags = np.empty(n, dtype=np.uint8)
+        rays = np.empty(n, dtype=_capi.RAY_DTYPE)
         rs_ptr = None
         if rng_states is not None:
             rs = np.ascontiguousarray(rng_states, dtype=np.uint32)
             if rs.shape != (n, 4):
                 raise ValueError("rng_states must be (n, 4) uint32")
             rs_ptr = rs.ctypes.data
-        rp = _capi.RayPlanes(*[planes[k].ctypes.data for k in range(7)], flags.ctypes.data)
-        self._check(self._lib.zoic_create_rays_host(self._h, n, s.ctypes.data, rs_ptr, int(ray_index_base), rp))
-        return dict(planes=planes, origin=planes[0:3], dir=planes[3:6], weight=planes[6], flags=flags,
-                    tries=((flags >> 1) & 31).astype(np.int32))
+        self._check(self._lib.zoic_create_rays_host(self._h, n, s.ctypes.data, rs_ptr, int(ray_index_base), rays.ctypes.data))
+        return rays_to_dict(rays)
 
     def _create_rays_torch(self, samples, rng_states, ray_index_base, out, stream):
         import torch
@@ -162,25 +168,23 @@ class ZoicCamera:
             raise ValueError("torch samples must live on the GPU (use numpy for host buffers)")
         n = samples.shape[0]
         if out is None:
-            out = dict(planes=torch.empty((7, n), dtype=torch.float32, device=samples.device),
-                       flags=torch.empty(n, dtype=torch.uint8, device=samples.device))
-        planes, flags = out["planes"], out["flags"]
+            out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device=samples.device))
+        rays = out["rays"]
         rs_ptr = None
         if rng_states is not None:
             if rng_states.dtype not in (torch.int32, torch.uint32) or tuple(rng_states.shape) != (n, 4):
                 raise ValueError("rng_states must be (n,4) int32/uint32 on the device")
             rs_ptr = rng_states.data_ptr()
         st = stream if stream is not None else torch.cuda.current_stream(samples.device).cuda_stream
-        rp = _capi.RayPlanes(*[planes[k].data_ptr() for k in range(7)], flags.data_ptr())
-        self._check(self._lib.zoic_create_rays_device(self._h, n, samples.data_ptr(), rs_ptr, int(ray_index_base), rp,
-                                                      C.c_void_p(st)))
-        out.update(origin=planes[0:3], dir=planes[3:6], weight=planes[6])
+        self._check(self._lib.zoic_create_rays_device(self._h, n, samples.data_ptr(), rs_ptr, int(ray_index_base),
+                                                      rays.data_ptr(), C.c_void_p(st)))
+        out.update(origin=rays[:, 0:3].t(), dir=rays[:, 3:6].t(), weight=rays[:, 6], planes=rays[:, 0:7].t(),
+                   flags=rays[:, 7].view(torch.int32))
         return out
 
-    def create_rays_device_ptr(self, n, d_samples, d_planes7, d_flags, d_rng=None, ray_index_base=0, stream=0):
-        """Raw-pointer form of zoic_create_rays_device: d_planes7 is one allocation of 7*n floats."""
-        rp = _capi.RayPlanes(*[d_planes7 + 4 * n * k for k in range(7)], d_flags)
-        self._check(self._lib.zoic_create_rays_device(self._h, n, d_samples, d_rng, int(ray_index_base), rp,
+    def create_rays_device_ptr(self, n, d_samples, d_rays, d_rng=None, ray_index_base=0, stream=0):
+        """Raw-pointer form of zoic_create_rays_device (d_rays: n x 32-byte zoic_ray records)."""
+        self._check(self._lib.zoic_create_rays_device(self._h, n, d_samples, d_rng, int(ray_index_base), d_rays,
                                                       C.c_void_p(stream)))
 
     def create_ray(self, sx, sy, lensx, lensy, tid=0):

@@ -82,13 +82,14 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     KolbTable kolb{};
     ThinTable thin{};
     // device state
-    DeviceBuffer<float> dCdfRow, dCdfColumn, dPyramid;
+    DeviceBuffer<float> dCdfRow, dCdfColumn, dPyramid, dBokehLds;
     DeviceBuffer<int32_t> dRowIdx, dColIdx;
     BokehTables bokehDev{};
     DeviceCounters *dCounters = nullptr;
-    DeviceBuffer<float> dSamples, dPlanes, dInputs7, dProbeU, dProbeV;
+    DeviceBuffer<float> dSamples, dInputs7, dProbeU, dProbeV;
+    DeviceBuffer<RayRecord> dRays;
     DeviceBuffer<uint32_t> dRng;
-    DeviceBuffer<uint8_t> dFlags, dProbeOk;
+    DeviceBuffer<uint8_t> dProbeOk;
     unsigned int *dProbeTir = nullptr;
     unsigned int *dWorkCursor = nullptr;
 };
@@ -228,6 +229,38 @@ zoic_status upload_bokeh(zoic_camera *cam)
         B.colCount[j] = cshape.count[j];
     }
     B.levels = levels;
+    // LDS image + packed column level 0 for two-level images (both dimensions <= 256)
+    if (levels == 2 && rp.levels <= 2 && cp.levels <= 2) {
+        const int rs0 = rshape.stride[0], chunks = (im.x + 15) / 16;
+        const size_t ldsWords = 16 + static_cast<size_t>(rs0) * 2 + y * 16;
+        const size_t packedWords = y * static_cast<size_t>(chunks) * 32;
+        std::vector<float> img(ldsWords + packedWords);
+        float *p = img.data();
+        std::memcpy(p, rbase[1], 16 * sizeof(float));                               // rowTop
+        std::memcpy(p + 16, rbase[0], rs0 * sizeof(float));                         // rowL0
+        int32_t *ri = reinterpret_cast<int32_t *>(p + 16 + rs0);
+        for (int i = 0; i < rs0; ++i) ri[i] = i < im.y ? im.rowIndices[i] : 0;      // rowIndices
+        for (size_t r = 0; r < y; ++r) std::memcpy(p + 16 + 2 * rs0 + r * 16, cbase[1] + r * cshape.stride[1], 16 * sizeof(float));  // colTop
+        float *pk = p + ldsWords;
+        const float inf = INFINITY;
+        for (size_t r = 0; r < y; ++r)
+            for (int c = 0; c < chunks; ++c) {
+                float *line = pk + (r * chunks + c) * 32;
+                int32_t *iline = reinterpret_cast<int32_t *>(line + 16);
+                for (int k = 0; k < 16; ++k) {
+                    const int e = c * 16 + k;
+                    line[k] = e < im.x ? im.cdfColumn[r * im.x + e] : inf;
+                    iline[k] = e < im.x ? im.columnIndices[r * im.x + e] - static_cast<int32_t>(r * im.x) : 0;
+                }
+            }
+        ZOIC_HIP(cam->dBokehLds.reserve(img.size()));
+        ZOIC_HIP(hipMemcpy(cam->dBokehLds.ptr, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+        B.ldsImage = cam->dBokehLds.ptr;
+        B.colPacked = cam->dBokehLds.ptr + ldsWords;
+        B.ldsWords = static_cast<int32_t>(ldsWords);
+        B.rowStride0 = rs0;
+        B.colChunks = chunks;
+    }
     return ZOIC_OK;
 }
 
@@ -323,8 +356,8 @@ void zoic_camera_destroy(zoic_camera *cam)
     if (!cam) return;
     if (cam->device == ZOIC_DEVICE_NONE) { delete cam; return; }
     (void)hipSetDevice(cam->device);
-    cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release();
-    cam->dSamples.release(); cam->dPlanes.release(); cam->dInputs7.release(); cam->dRng.release(); cam->dFlags.release();
+    cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release(); cam->dBokehLds.release();
+    cam->dSamples.release(); cam->dRays.release(); cam->dInputs7.release(); cam->dRng.release();
     cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release();
     if (cam->dProbeTir) (void)hipFree(cam->dProbeTir);
     if (cam->dCounters) (void)hipFree(cam->dCounters);
@@ -455,7 +488,7 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
 }
 
 zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng_states,
-                                    uint64_t ray_index_base, zoic_ray_planes out, void *stream)
+                                    uint64_t ray_index_base, zoic_ray *d_rays, void *stream)
 {
     if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
     if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera: rays need a gfx950 device (no CPU path)");
@@ -464,8 +497,10 @@ zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d
     if (!d_samples) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_samples is NULL");
     if (reinterpret_cast<uintptr_t>(d_samples) & 15u) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_samples must be 16-byte aligned");
     if (d_rng_states && (reinterpret_cast<uintptr_t>(d_rng_states) & 15u)) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_rng_states must be 16-byte aligned");
+    if (!d_rays || (reinterpret_cast<uintptr_t>(d_rays) & 15u)) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_rays must be non-NULL and 16-byte aligned");
+    static_assert(sizeof(zoic_ray) == sizeof(RayRecord), "zoic_ray layout");
     ZOIC_HIP(hipSetDevice(cam->device));
-    RayPlanes planes{out.ox, out.oy, out.oz, out.dx, out.dy, out.dz, out.weight, out.flags};
+    RayRecord *planes = reinterpret_cast<RayRecord *>(d_rays);
     int rc = 0;
     switch (cam->params.p.lensModel) {
     case ZOIC_RAYTRACED:
@@ -483,7 +518,7 @@ zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d
 }
 
 zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_samples, const uint32_t *h_rng_states,
-                                  uint64_t ray_index_base, zoic_ray_planes out)
+                                  uint64_t ray_index_base, zoic_ray *h_rays)
 {
     if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
     if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera: rays need a gfx950 device (no CPU path)");
@@ -491,9 +526,9 @@ zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_s
     if (n == 0) return ZOIC_OK;
     if (!h_samples) return fail(ZOIC_ERR_INVALID_ARGUMENT, "h_samples is NULL");
     ZOIC_HIP(hipSetDevice(cam->device));
+    if (!h_rays) return fail(ZOIC_ERR_INVALID_ARGUMENT, "h_rays is NULL");
     ZOIC_HIP(cam->dSamples.reserve(n * 4));
-    ZOIC_HIP(cam->dPlanes.reserve(n * 7));
-    ZOIC_HIP(cam->dFlags.reserve(n));
+    ZOIC_HIP(cam->dRays.reserve(n));
     ZOIC_HIP(hipMemcpy(cam->dSamples.ptr, h_samples, n * 16, hipMemcpyHostToDevice));
     const uint32_t *dRng = nullptr;
     if (h_rng_states) {
@@ -501,14 +536,10 @@ zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_s
         ZOIC_HIP(hipMemcpy(cam->dRng.ptr, h_rng_states, n * 16, hipMemcpyHostToDevice));
         dRng = cam->dRng.ptr;
     }
-    float *P = cam->dPlanes.ptr;
-    zoic_ray_planes d{P, P + n, P + 2 * n, P + 3 * n, P + 4 * n, P + 5 * n, P + 6 * n, cam->dFlags.ptr};
-    if (zoic_status s = zoic_create_rays_device(cam, n, cam->dSamples.ptr, dRng, ray_index_base, d, nullptr)) return s;
+    if (zoic_status s = zoic_create_rays_device(cam, n, cam->dSamples.ptr, dRng, ray_index_base,
+                                                reinterpret_cast<zoic_ray *>(cam->dRays.ptr), nullptr)) return s;
     ZOIC_HIP(hipDeviceSynchronize());
-    float *dst[7] = {out.ox, out.oy, out.oz, out.dx, out.dy, out.dz, out.weight};
-    for (int k = 0; k < 7; ++k)
-        if (dst[k]) ZOIC_HIP(hipMemcpy(dst[k], P + k * n, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (out.flags) ZOIC_HIP(hipMemcpy(out.flags, cam->dFlags.ptr, n, hipMemcpyDeviceToHost));
+    ZOIC_HIP(hipMemcpy(h_rays, cam->dRays.ptr, n * sizeof(zoic_ray), hipMemcpyDeviceToHost));
     return ZOIC_OK;
 }
 
@@ -524,26 +555,23 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
     ZOIC_HIP(hipSetDevice(cam->device));
     ZOIC_HIP(cam->dInputs7.reserve(n * 7));
     ZOIC_HIP(cam->dSamples.reserve(n * 4));
-    ZOIC_HIP(cam->dPlanes.reserve(n * 7));
-    ZOIC_HIP(cam->dFlags.reserve(n));
+    ZOIC_HIP(cam->dRays.reserve(n));
     ZOIC_HIP(hipMemcpy(cam->dInputs7.ptr, inputs, n * sizeof(zoic_camera_input), hipMemcpyHostToDevice));
     if (int rc = launch_pack_inputs(cam->dInputs7.ptr, cam->dSamples.ptr, n, nullptr))
         return fail(ZOIC_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-    float *P = cam->dPlanes.ptr;
-    zoic_ray_planes d{P, P + n, P + 2 * n, P + 3 * n, P + 4 * n, P + 5 * n, P + 6 * n, cam->dFlags.ptr};
-    if (zoic_status s = zoic_create_rays_device(cam, n, cam->dSamples.ptr, nullptr, ray_index_base, d, nullptr)) return s;
-    std::vector<float> h(n * 7);
-    std::vector<uint8_t> hf(n);
-    ZOIC_HIP(hipMemcpy(h.data(), P, n * 7 * sizeof(float), hipMemcpyDeviceToHost));
-    ZOIC_HIP(hipMemcpy(hf.data(), cam->dFlags.ptr, n, hipMemcpyDeviceToHost));
+    if (zoic_status s = zoic_create_rays_device(cam, n, cam->dSamples.ptr, nullptr, ray_index_base,
+                                                reinterpret_cast<zoic_ray *>(cam->dRays.ptr), nullptr)) return s;
+    std::vector<zoic_ray> h(n);
+    ZOIC_HIP(hipMemcpy(h.data(), cam->dRays.ptr, n * sizeof(zoic_ray), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; ++i) {
         zoic_camera_output &o = outputs[i];
-        o.origin = zoic_vec3{h[i], h[n + i], h[2 * n + i]};
-        o.dir = zoic_vec3{h[3 * n + i], h[4 * n + i], h[5 * n + i]};
-        const float w = h[6 * n + i];
+        const zoic_ray &r = h[i];
+        o.origin = zoic_vec3{r.ox, r.oy, r.oz};
+        o.dir = zoic_vec3{r.dx, r.dy, r.dz};
+        const float w = r.weight;
         if (w == 0.0f) o.weight[0] = o.weight[1] = o.weight[2] = 0.0f;  // output.weight = 0.0f, zoic.cpp:1825/1952
         else if (w != 1.0f) { o.weight[0] *= w; o.weight[1] *= w; o.weight[2] *= w; }  // exposure factor
-        if (hf[i] & 1u) { o.dOdy = o.origin; o.dDdy = o.dir; }  // zoic.cpp:1974-1977
+        if (r.flags & 1u) { o.dOdy = o.origin; o.dDdy = o.dir; }  // zoic.cpp:1974-1977
     }
     return ZOIC_OK;
 }

@@ -58,4 +58,37 @@ __device__ __forceinline__ V2 bokeh_sample_device(const BokehTables &B, int x, i
     return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
 }
 
+// Lens sample with the row tables and the column pyramid tops resident in LDS (`lds` = the workgroup's copy of
+// BokehTables::ldsImage).  Identical indices to bokeh_sample_device / std::upper_bound.
+__device__ __forceinline__ V2 bokeh_sample_lds(const BokehTables &B, const float *lds, int x, int y, float uRow, float uCol)
+{
+    const float *rowTop = lds, *rowL0 = lds + 16;
+    const int32_t *rowIdx = reinterpret_cast<const int32_t *>(lds + 16 + B.rowStride0);
+    const float *colTop = lds + 16 + 2 * B.rowStride0;
+    int r = chunk_count_le(rowTop, uRow);                       // chunk of the row CDF (16 chunk maxima, broadcast read)
+    if (r >= B.rowCount[1]) r = y;                              // every row mass <= u
+    else {
+        r = r * 16 + chunk_count_le(rowL0 + r * 16, uRow);
+        if (r > y) r = y;
+    }
+    if (r >= y) r = y - 1;
+    const int row = rowIdx[r];
+    int c = chunk_count_le(colTop + row * 16, uCol);
+    int col;
+    if (c >= B.colCount[1]) {                                   // every entry of this row's CDF <= u: clamp to the last
+        const int32_t *iline = reinterpret_cast<const int32_t *>(B.colPacked + (static_cast<size_t>(row) * B.colChunks + (x - 1) / 16) * 32 + 16);
+        col = iline[(x - 1) & 15];
+    } else {
+        const float *line = B.colPacked + (static_cast<size_t>(row) * B.colChunks + c) * 32;
+        int k = chunk_count_le(line, uCol);                     // one 64-byte global read; < 16 because the chunk max > u
+        int e = c * 16 + k;
+        if (e >= x) e = x - 1;
+        const float *line2 = B.colPacked + (static_cast<size_t>(row) * B.colChunks + (e >> 4)) * 32;
+        col = reinterpret_cast<const int32_t *>(line2 + 16)[e & 15];   // same 128-byte line: L1 hit
+    }
+    const float flippedRow = static_cast<float>(col - ((y - 1) / 2));
+    const float flippedColumn = static_cast<float>(row - ((x - 1) / 2)) * -1.0f;
+    return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
+}
+
 }  // namespace zoic

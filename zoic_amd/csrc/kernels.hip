@@ -5,8 +5,8 @@
 // a grid capped at 8 workgroups per CU that strides over the sample buffer.  The lens prescription and the
 // exit-pupil LUT arrive as a by-value kernel argument: wave-uniform, fetched by s_load through the scalar
 // cache, indexed by the (uniform) surface counter -- no LDS and no VGPRs spent on tables.  Sample loads are
-// one 16-byte global_load_dwordx4 per lane (1 KiB per wave instruction); results leave as seven coalesced
-// 4-byte planes + a flag byte.  The path is scalar FP32 per ray: no contraction to feed MFMA.
+// one 16-byte global_load_dwordx4 per lane (1 KiB per wave instruction); results leave as one 32-byte record
+// per ray (two 16-byte stores per lane).  The path is scalar FP32 per ray: no contraction to feed MFMA.
 //
 // STRICT = the reference's operation order and f64 intermediates, no FMA contraction (see optics.hpp): bit-exact
 // against the CPU oracle.  The FAST variant lives in kolb_fast.hip.
@@ -17,6 +17,7 @@
 
 #include "device_search.hpp"
 #include "kernels.hpp"
+#include "ray_store.hpp"
 #include "optics.hpp"
 
 #pragma STDC FP_CONTRACT OFF
@@ -24,18 +25,6 @@
 namespace zoic {
 
 constexpr int kBlock = 256;
-
-__device__ __forceinline__ void store_ray(const RayPlanes &out, uint64_t i, V3 o, V3 d, float w, uint8_t flags)
-{
-    if (out.ox) out.ox[i] = o.x;
-    if (out.oy) out.oy[i] = o.y;
-    if (out.oz) out.oz[i] = o.z;
-    if (out.dx) out.dx[i] = d.x;
-    if (out.dy) out.dy[i] = d.y;
-    if (out.dz) out.dz[i] = d.z;
-    if (out.weight) out.weight[i] = w;
-    if (out.flags) out.flags[i] = flags;
-}
 
 // sum three per-lane counters over the workgroup, one atomic per counter per workgroup
 __device__ __forceinline__ void flush_counters(DeviceCounters *c, uint32_t succ, uint32_t vign, uint32_t tir)
@@ -68,7 +57,7 @@ __device__ __forceinline__ V2 sample_lens(bool useImage, const BokehTables &B, i
 __global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTable T, const BokehTables B,
                                                                   const float4 *__restrict__ samples,
                                                                   const uint4 *__restrict__ rngStates, uint64_t rayBase,
-                                                                  uint64_t n, const RayPlanes out, DeviceCounters *counters)
+                                                                  uint64_t n, RayRecord *__restrict__ out, DeviceCounters *counters)
 {
     uint32_t succ = 0, vign = 0, tir = 0;
     const bool useImage = T.useImage != 0;
@@ -117,9 +106,8 @@ __global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTabl
         float w = 1.0f;
         if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
         if (T.exposureOn) w *= T.exposureMul;                      // zoic.cpp:1981-1987
-        const V3 oo{o.x * -1.0f, o.y * -1.0f, o.z * -1.0f};        // zoic.cpp:1960-1961
-        const V3 dd{d.x * -1.0f, d.y * -1.0f, d.z * -1.0f};
-        store_ray(out, i, oo, dd, w, static_cast<uint8_t>((tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1) | (lutMiss << 6)));
+        store_ray_record(out, i, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,  // zoic.cpp:1960-1961
+                         (tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1) | (lutMiss << 6));
     }
     flush_counters(counters, succ, vign, tir);
 }
@@ -136,7 +124,7 @@ __device__ __forceinline__ bool optical_vignet_pass(const ThinTable &T, V3 origi
 __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, const BokehTables B,
                                                            const float4 *__restrict__ samples,
                                                            const uint4 *__restrict__ rngStates, uint64_t rayBase, uint64_t n,
-                                                           const RayPlanes out, DeviceCounters *counters)
+                                                           RayRecord *__restrict__ out, DeviceCounters *counters)
 {
     uint32_t succ = 0, vign = 0;
     const bool useImage = T.useImage != 0;
@@ -174,7 +162,8 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
         }
         dir.z = dir.z * -1.0f;                     // zoic.cpp:1845
         if (T.exposureOn) w *= T.exposureMul;
-        store_ray(out, i, origin, dir, w, static_cast<uint8_t>((tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1)));
+        store_ray_record(out, i, origin.x, origin.y, origin.z, dir.x, dir.y, dir.z, w,
+                         (tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1));
     }
     flush_counters(counters, succ, vign, 0u);
 }
@@ -239,9 +228,9 @@ static inline unsigned grid_for(uint64_t n)
 }
 
 int launch_kolb_fast(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream);
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, void *stream);
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                       uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                       uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                        bool fast, void *stream);
 
 // ZOIC_KOLB_VARIANT=simple selects the one-sample-per-lane kernels (A/B baseline); default: persistent lane refill
@@ -252,7 +241,7 @@ static bool use_simple_variant()
 }
 
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                      bool fast, void *stream)
 {
     if (n == 0) return 0;
@@ -265,7 +254,7 @@ int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const flo
 }
 
 int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream)
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, void *stream)
 {
     if (n == 0) return 0;
     hipLaunchKernelGGL(thin_rays_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,

@@ -7,10 +7,16 @@
 
 namespace zoic {
 
-struct RayPlanes {  // device pointers, any may be null
-    float *ox, *oy, *oz, *dx, *dy, *dz, *weight;
-    uint8_t *flags;
+// One finished camera ray: a 32-byte record, so the lane that finishes a ray writes exactly one aligned 32-byte
+// sector with two 16-byte stores.  (The first kernels wrote seven 4-byte planes; with persistent waves the finishing
+// lanes hold non-consecutive rays and rocprof measured 2.6x write amplification from partially written lines --
+// profiles/r01_fast_v1.  Same layout as zoic_ray in include/zoic_amd.h.)
+struct alignas(16) RayRecord {
+    float ox, oy, oz, dx, dy, dz, weight;
+    uint32_t flags;  // bit0 retried, bits1-5 tries, bit6 outside the exit-pupil LUT
 };
+static_assert(sizeof(RayRecord) == 32, "ray record is one 32-byte sector");
+
 
 struct DeviceCounters {  // zoic.cpp:533-534: succesRays, vignettedRays, totalInternalReflection
     unsigned long long succes, vignetted, tir;
@@ -19,12 +25,12 @@ struct DeviceCounters {  // zoic.cpp:533-534: succesRays, vignettedRays, totalIn
 // camera_create_ray, RAYTRACED branch (zoic.cpp:1850-1964) over n samples.  fast=false: strict arithmetic.
 // d_workCursor: one device word the persistent kernel uses as its chunk cursor (zeroed on the stream per launch).
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                      bool fast, void *stream);
 
 // camera_create_ray, THINLENS branch (zoic.cpp:1771-1846)
 int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream);
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, void *stream);
 
 // synthetic camera samples: id=(py*W+px)*spp+s, pcg-hashed jitter and lens samples
 int launch_generate_samples(float *d_samples, uint64_t rayBase, uint64_t n, uint32_t width, uint32_t height, uint32_t spp,

@@ -14,6 +14,7 @@
 #include "device_search.hpp"
 #include "fast_optics.hpp"
 #include "kernels.hpp"
+#include "ray_store.hpp"
 #include "optics.hpp"
 
 #pragma clang fp contract(fast)
@@ -31,7 +32,7 @@ __device__ __forceinline__ V2 sample_lens_f32(bool useImage, const BokehTables &
 __global__ __launch_bounds__(kBlockF) void kolb_rays_fast_kernel(const KolbTable T, const BokehTables B,
                                                                  const float4 *__restrict__ samples,
                                                                  const uint4 *__restrict__ rngStates, uint64_t rayBase, uint64_t n,
-                                                                 const RayPlanes out, DeviceCounters *counters)
+                                                                 RayRecord *__restrict__ out, DeviceCounters *counters)
 {
     uint32_t succ = 0, vign = 0, tir = 0;
     const bool useImage = T.useImage != 0;
@@ -78,15 +79,8 @@ __global__ __launch_bounds__(kBlockF) void kolb_rays_fast_kernel(const KolbTable
         float w = 1.0f;
         if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ;
         if (T.exposureOn) w *= T.exposureMul;
-        const uint8_t flags = static_cast<uint8_t>((tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1) | (lutMiss << 6));
-        if (out.ox) out.ox[i] = -o.x;
-        if (out.oy) out.oy[i] = -o.y;
-        if (out.oz) out.oz[i] = -o.z;
-        if (out.dx) out.dx[i] = -d.x;
-        if (out.dy) out.dy[i] = -d.y;
-        if (out.dz) out.dz[i] = -d.z;
-        if (out.weight) out.weight[i] = w;
-        if (out.flags) out.flags[i] = flags;
+        const uint32_t flags = (tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1) | (lutMiss << 6);
+        store_ray_record(out, i, -o.x, -o.y, -o.z, -d.x, -d.y, -d.z, w, flags);
     }
     // workgroup reduction of the three counters, one atomic each
     __shared__ uint32_t part[3][kBlockF / 64];
@@ -107,7 +101,7 @@ __global__ __launch_bounds__(kBlockF) void kolb_rays_fast_kernel(const KolbTable
 }
 
 int launch_kolb_fast(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, void *stream)
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, void *stream)
 {
     const uint64_t blocks = (n + kBlockF - 1) / kBlockF;
     const unsigned grid = static_cast<unsigned>(blocks < 2048 ? (blocks ? blocks : 1) : 2048);

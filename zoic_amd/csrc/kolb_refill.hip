@@ -18,14 +18,15 @@
 // one-sample-per-lane kernel and to the CPU oracle.
 //
 // Tables: the lens prescription + LUT arrive by value (SGPRs via s_load, see tables.hpp); bokeh CDFs are searched
-// through the 16-ary pyramid (device_search.hpp).  Samples: one global_load_dwordx4 per refilled lane.  Rays: seven
-// 4-byte planes + a flag byte, written by the lanes that finished in this pass (their indices are consecutive within
-// a 64-sample window, so the stores land in a handful of cache lines).
+// through the 16-ary pyramid (device_search.hpp).  Samples: one global_load_dwordx4 per refilled lane.  Rays: one
+// 32-byte record per ray (two 16-byte stores), written by the lane that finished it -- a whole sector per lane, so
+// the scattered completion order causes no partial-line write-backs.
 #include <hip/hip_runtime.h>
 
 #include "device_search.hpp"
 #include "fast_optics.hpp"
 #include "kernels.hpp"
+#include "ray_store.hpp"
 #include "optics.hpp"
 
 #pragma STDC FP_CONTRACT OFF
@@ -37,24 +38,40 @@ constexpr int kWavesPerBlock = kRefillBlock / 64;
 constexpr uint32_t kChunkRays = 1024;  // samples a wave claims per atomic on the work cursor (16 passes of fresh work)
 
 template <bool STRICT>
-__device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, float u, float v)
+__device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v)
 {
-    if (T.useImage) return bokeh_sample_device(B, T.bokehW, T.bokehH, u, v);
+    if (T.useImage) {
+        if (bokehLds) return bokeh_sample_lds(B, bokehLds, T.bokehW, T.bokehH, u, v);
+        return bokeh_sample_device(B, T.bokehW, T.bokehH, u, v);
+    }
     if constexpr (STRICT) return concentric_disk(u, v);
     else return concentric_disk_f32(u, v);
 }
+
+extern __shared__ __align__(16) float zoicDynLds[];
 
 template <bool STRICT>
 __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTable T, const BokehTables B,
                                                                    const float4 *__restrict__ samples,
                                                                    const uint4 *__restrict__ rngStates, uint64_t rayBase,
-                                                                   uint32_t n, const RayPlanes out, DeviceCounters *counters,
-                                                                   unsigned int *__restrict__ workCursor)
+                                                                   uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters,
+                                                                   unsigned int *__restrict__ workCursor, uint32_t ldsWords)
 {
     const uint32_t lane = threadIdx.x & 63u;
+    // bokeh row tables + column-pyramid tops -> LDS, once per workgroup (launch passes ldsWords*4 dynamic bytes or 0)
+    const float *bokehLds = nullptr;
+    if (ldsWords > 0) {
+        for (uint32_t i = threadIdx.x; i < ldsWords; i += kRefillBlock) zoicDynLds[i] = B.ldsImage[i];
+        __syncthreads();
+        bokehLds = zoicDynLds;
+    }
     // wave-uniform work window [next, end): a chunk of kChunkRays consecutive samples claimed from the global cursor
     uint32_t next = 0, end = 0;
     bool exhausted = false;
+    // sample prefetch window: lane l holds samples[winBase + l], loaded one pass ahead of its use so the HBM latency
+    // hides under the trace; refilled lanes fetch their sample from lane `rank` with ds_bpermute (winBase == next)
+    float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t winBase = 0xffffffffu;
 
     // per-lane ray state, alive across passes
     bool active = false, fresh = false, dead = false;
@@ -76,13 +93,20 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
                 next = static_cast<uint32_t>(begin);
                 end = (begin + kChunkRays < n) ? static_cast<uint32_t>(begin + kChunkRays) : n;
             }
+            if (winBase != next) {  // first use of a chunk: the window has to be fetched in line (once per kChunkRays)
+                const uint32_t wi = next + lane;
+                win = samples[wi < n ? wi : n - 1];
+                winBase = next;
+            }
             const uint32_t avail = end - next;
             const uint32_t nfree = static_cast<uint32_t>(__popcll(freeMask));
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(freeMask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(freeMask), 0u));
+            // my sample sits in lane `rank` of the window (all lanes take part in the permute)
+            const float4 s = make_float4(__shfl(win.x, rank, 64), __shfl(win.y, rank, 64), __shfl(win.z, rank, 64),
+                                         __shfl(win.w, rank, 64));  // (sx, sy, lensx, lensy)
             if (!active && rank < avail) {
                 idx = next + rank;
-                const float4 s = samples[idx];  // (sx, sy, lensx, lensy)
                 if (rngStates) { const uint4 r = rngStates[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
                 else rng = rng_for_ray(T.seed, rayBase + idx);
                 o0x = s.x * T.halfSensor;  // zoic.cpp:1853-1854
@@ -111,6 +135,11 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
                 active = true; fresh = true;
             }
             next += (nfree < avail) ? nfree : avail;
+            if (next < end) {       // re-base the window on the new cursor; consumed by the NEXT pass
+                const uint32_t wi = next + lane;
+                win = samples[wi < n ? wi : n - 1];
+                winBase = next;
+            }
             if (nfree <= avail) break;
             freeMask = __ballot(!active);
         }
@@ -123,7 +152,7 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
                 v = rng_unit(xor128(rng));
                 ++tries;
             }
-            V2 lens = lens_sample<STRICT>(T, B, u, v);
+            V2 lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
             // the dead-pixel shortcut needs a finite first sample (NaN*0 would differ from later tries)
             const bool finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
             V3 o{o0x, o0y, T.originShift}, d;
@@ -150,14 +179,8 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
                 float w = 1.0f;
                 if (tries > static_cast<uint32_t>(kMaxTries)) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
                 if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
-                if (out.ox) out.ox[idx] = o.x * -1.0f;   // zoic.cpp:1960-1961
-                if (out.oy) out.oy[idx] = o.y * -1.0f;
-                if (out.oz) out.oz[idx] = o.z * -1.0f;
-                if (out.dx) out.dx[idx] = d.x * -1.0f;
-                if (out.dy) out.dy[idx] = d.y * -1.0f;
-                if (out.dz) out.dz[idx] = d.z * -1.0f;
-                if (out.weight) out.weight[idx] = w;
-                if (out.flags) out.flags[idx] = static_cast<uint8_t>((tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6));
+                store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,  // zoic.cpp:1960-1961
+                                 (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6));
                 active = false;
             }
         }
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
 }
 
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                       uint64_t rayBase, uint64_t n, const RayPlanes &out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                       uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                        bool fast, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -194,18 +217,18 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         const uint64_t chunks = (m + kChunkRays - 1) / kChunkRays;
         const uint64_t wantBlocks = (chunks + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned grid = static_cast<unsigned>(wantBlocks < 2048 ? (wantBlocks ? wantBlocks : 1) : 2048);
-        RayPlanes o = out;
-        if (o.ox) o.ox += done; if (o.oy) o.oy += done; if (o.oz) o.oz += done;
-        if (o.dx) o.dx += done; if (o.dy) o.dy += done; if (o.dz) o.dz += done;
-        if (o.weight) o.weight += done; if (o.flags) o.flags += done;
+        RayRecord *o = out + done;
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
         const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
+        // bokeh tables in LDS when the image is on and its LDS image fits comfortably (<= 40 KB keeps 4 workgroups per CU)
+        const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
+        const size_t ldsBytes = static_cast<size_t>(ldsWords) * sizeof(float);
         if (fast)
-            hipLaunchKernelGGL(kolb_refill_kernel<false>, dim3(grid), dim3(kRefillBlock), 0, st, table, bokeh, sp, rp, rayBase + done,
-                               static_cast<uint32_t>(m), o, d_counters, d_workCursor);
+            hipLaunchKernelGGL(kolb_refill_kernel<false>, dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,
+                               rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords);
         else
-            hipLaunchKernelGGL(kolb_refill_kernel<true>, dim3(grid), dim3(kRefillBlock), 0, st, table, bokeh, sp, rp, rayBase + done,
-                               static_cast<uint32_t>(m), o, d_counters, d_workCursor);
+            hipLaunchKernelGGL(kolb_refill_kernel<true>, dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,
+                               rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords);
         e = hipGetLastError();
         if (e != hipSuccess) return static_cast<int>(e);
     }

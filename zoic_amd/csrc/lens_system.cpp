@@ -239,6 +239,14 @@ void LensSystem::fill_surfaces(KolbTable &t) const
         if (static_cast<double>(f) > lim) f = std::nextafterf(f, -INFINITY);
         s.housing2 = f;
         s.invRadius = 1.0f / r.radius;
+        FastSurface &q = t.fsurf[i];
+        q = FastSurface{};
+        q.center = s.center; q.radius2 = s.radius2; q.sign = s.sign; q.housing2 = s.housing2; q.invRadius = s.invRadius;
+        q.eta = s.eta;
+        const double eta = s.eta, invR = 1.0 / static_cast<double>(r.radius);
+        q.etaInvAbsR = static_cast<float>(eta * std::fabs(invR));
+        q.e2InvR2 = static_cast<float>(eta * eta * invR * invR);
+        q.oneMinusEta2 = static_cast<float>(1.0 - eta * eta);
     }
 }
 

@@ -120,7 +120,13 @@ ZOIC_HD V2 concentric_disk(float ox, float oy)
 ZOIC_HD bool trace_lens_strict(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
 {
     const int n = T.lensCount;
-    for (int i = 0; i < n; ++i) {
+    for (int ii = 0; ii < n; ++ii) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // all lanes still looping are at the same surface: keep the index (and the table fetch) scalar
+        const int i = __builtin_amdgcn_readfirstlane(ii);
+#else
+        const int i = ii;
+#endif
         const Surface S = T.surf[i];
         // raySphereIntersection(.., reverse=false, tracingRealRays=true), zoic.cpp:973-995
         V3 u = normalize3(d);

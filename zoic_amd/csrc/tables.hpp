@@ -35,6 +35,21 @@ struct Surface {
     uint32_t tirPossible;  // ior1 > ior2 (zoic.cpp:1019)
 };
 
+// The same interface pre-digested for the FAST kernel (fast_optics.hpp): with a unit direction the Snell step needs
+// no dot product -- cos(incidence) = thc/|R| -- so everything that multiplies thc or thc^2 is folded on the host.
+struct FastSurface {
+    float center;        // sphere centre z
+    float radius2;       // R^2
+    float sign;          // sgn(R)
+    float housing2;      // clip limit on x^2+y^2 (same f32 as Surface::housing2)
+    float invRadius;     // 1/R
+    float eta;           // n1/n2
+    float etaInvAbsR;    // eta/|R|          : eta*cos(i) = thc * etaInvAbsR
+    float e2InvR2;       // eta^2/R^2        : 1 - cs2 = oneMinusEta2 + e2InvR2 * thc^2
+    float oneMinusEta2;  // 1 - eta^2
+    float pad0, pad1, pad2;
+};
+
 struct KolbTable {
     int32_t lensCount;
     int32_t apertureElement;
@@ -52,6 +67,7 @@ struct KolbTable {
     uint32_t seed;
     int32_t pad0;
     Surface surf[kMaxSurfaces];
+    FastSurface fsurf[kMaxSurfaces];
     float lutMaxScale[kLutEntries];  // boundingBox2d::getMaxScale per LUT entry (zoic.cpp:503-517)
     float lutCentroidX[kLutEntries]; // boundingBox2d::getCentroid().x          (zoic.cpp:495-498)
 };
@@ -84,6 +100,17 @@ struct BokehTables {
     int32_t rowCount[kBokehMaxLevels];       // valid entries per level of the row pyramid
     int32_t colCount[kBokehMaxLevels];       // valid entries per level of one column pyramid row
     int32_t levels;                          // 0: pyramid not built (CDF longer than 4096) -> binary search
+    // Two-level images (x, y <= 256): everything the row search needs plus the top level of every column pyramid is
+    // copied into LDS once per workgroup (ldsImage, ldsWords dwords):
+    //   [ rowTop 16 f | rowL0 rowStride0 f | rowIndices rowStride0 i32 | colTop y*16 f ]
+    // and level 0 of the column pyramids is packed with the pixel indices, one 128-byte line per 16-entry chunk:
+    //   colPacked[(row*colChunks + chunk)*32 + k] = cdf (k < 16) | columnIndices - row*x as i32 (k >= 16)
+    // so a lens sample costs 4 LDS round trips + 1 global line (+ an L1 hit) instead of 6 global round trips.
+    const float *ldsImage;
+    const float *colPacked;
+    int32_t ldsWords;      // 0: not available
+    int32_t rowStride0;    // ceil16(y)
+    int32_t colChunks;     // ceil(x/16)
 };
 
 }  // namespace zoic

@@ -22,36 +22,26 @@ def all_slabs(n_total, world, tile=TILE):
     return [slab_for_rank(n_total, r, world, tile) for r in range(world)]
 
 
-def gather_planes(planes, flags, n_total, dist, dst=0, tile=TILE):
-    """Gather every rank's (7, n_r) ray planes and (n_r,) flags on `dst`; returns ((7, n_total), (n_total,)) there,
-    (None, None) elsewhere.  Slabs may differ in size by one tile, so the exchange is grouped point-to-point
-    (the RCCL-friendly form of a gatherv: each peer->root transfer rides its own xGMI link)."""
+def gather_rays(rays, n_total, dist, dst=0, tile=TILE):
+    """Gather every rank's (n_r, k) ray-record tensor on `dst`; returns (n_total, k) there, None elsewhere.
+    Slabs may differ in size by one tile, so the exchange is grouped point-to-point (the RCCL-friendly form of a
+    gatherv: each peer->root transfer rides its own xGMI link)."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     slabs = all_slabs(n_total, world, tile)
     if rank == dst:
-        full = torch.empty((7, n_total), dtype=planes.dtype, device=planes.device)
-        fl = torch.empty((n_total,), dtype=flags.dtype, device=flags.device)
+        full = torch.empty((n_total,) + tuple(rays.shape[1:]), dtype=rays.dtype, device=rays.device)
         lo, hi = slabs[dst]
-        full[:, lo:hi] = planes
-        fl[lo:hi] = flags
-        reqs, bufs = [], []
+        full[lo:hi] = rays
+        reqs = []
         for r, (a, b) in enumerate(slabs):
             if r == dst or b <= a:
                 continue
-            pb = torch.empty((7, b - a), dtype=planes.dtype, device=planes.device)
-            fb = torch.empty((b - a,), dtype=flags.dtype, device=flags.device)
-            reqs.append(dist.irecv(pb, src=r))
-            reqs.append(dist.irecv(fb, src=r))
-            bufs.append((a, b, pb, fb))
+            reqs.append(dist.irecv(full[a:b], src=r))  # contiguous row range: received in place
         for q in reqs:
             q.wait()
-        for a, b, pb, fb in bufs:
-            full[:, a:b] = pb
-            fl[a:b] = fb
-        return full, fl
+        return full
     lo, hi = slabs[rank]
     if hi > lo:
-        dist.send(planes.contiguous(), dst=dst)
-        dist.send(flags.contiguous(), dst=dst)
-    return None, None
+        dist.send(rays.contiguous(), dst=dst)
+    return None
