@@ -231,13 +231,15 @@ zoic_status upload_bokeh(zoic_camera *cam)
     B.levels = levels;
     // LDS image + packed column level 0 for two-level images (both dimensions <= 256)
     if (levels == 2 && rp.levels <= 2 && cp.levels <= 2) {
-        const int rs0 = rshape.stride[0], chunks = (im.x + 15) / 16;
+        int rowLog2 = 4;
+        while ((1 << rowLog2) < im.y) ++rowLog2;
+        const int rs0 = 1 << rowLog2, chunks = (im.x + 15) / 16;
         const size_t ldsWords = 16 + static_cast<size_t>(rs0) * 2 + y * 16;
         const size_t packedWords = y * static_cast<size_t>(chunks) * 32;
         std::vector<float> img(ldsWords + packedWords);
         float *p = img.data();
-        std::memcpy(p, rbase[1], 16 * sizeof(float));                               // rowTop
-        std::memcpy(p + 16, rbase[0], rs0 * sizeof(float));                         // rowL0
+        std::memcpy(p, rbase[1], 16 * sizeof(float));                               // rowTop (kept for layout stability)
+        for (int i = 0; i < rs0; ++i) p[16 + i] = i < im.y ? im.cdfRow[i] : INFINITY;  // rowL0, +inf padded to 2^k
         int32_t *ri = reinterpret_cast<int32_t *>(p + 16 + rs0);
         for (int i = 0; i < rs0; ++i) ri[i] = i < im.y ? im.rowIndices[i] : 0;      // rowIndices
         for (size_t r = 0; r < y; ++r) std::memcpy(p + 16 + 2 * rs0 + r * 16, cbase[1] + r * cshape.stride[1], 16 * sizeof(float));  // colTop
@@ -259,6 +261,7 @@ zoic_status upload_bokeh(zoic_camera *cam)
         B.colPacked = cam->dBokehLds.ptr + ldsWords;
         B.ldsWords = static_cast<int32_t>(ldsWords);
         B.rowStride0 = rs0;
+        B.rowLog2 = rowLog2;
         B.colChunks = chunks;
     }
     return ZOIC_OK;

@@ -58,22 +58,31 @@ __device__ __forceinline__ V2 bokeh_sample_device(const BokehTables &B, int x, i
     return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
 }
 
+// Number of entries <= v in a non-decreasing LDS array of 2^log2n floats (+inf padded): the classic branch-free
+// descent, one ds_read_b32 + compare + select per level with a wave-uniform step.  == std::upper_bound index.
+// The kernels are VALU-issue bound, so 3 VALU per level beats the 32 compares+adds of counting a 16-chunk.
+__device__ __forceinline__ int lds_count_le_pow2(const float *a, int log2n, float v)
+{
+    int pos = 0;
+    for (int step = 1 << log2n; step > 0; step >>= 1) {
+        const int t = pos + step;
+        if (t <= (1 << log2n) && !(v < a[t - 1])) pos = t;
+    }
+    return pos;
+}
+
 // Lens sample with the row tables and the column pyramid tops resident in LDS (`lds` = the workgroup's copy of
 // BokehTables::ldsImage).  Identical indices to bokeh_sample_device / std::upper_bound.
+template <bool EXACT_DIVIDE>
 __device__ __forceinline__ V2 bokeh_sample_lds(const BokehTables &B, const float *lds, int x, int y, float uRow, float uCol)
 {
-    const float *rowTop = lds, *rowL0 = lds + 16;
+    const float *rowL0 = lds + 16;
     const int32_t *rowIdx = reinterpret_cast<const int32_t *>(lds + 16 + B.rowStride0);
     const float *colTop = lds + 16 + 2 * B.rowStride0;
-    int r = chunk_count_le(rowTop, uRow);                       // chunk of the row CDF (16 chunk maxima, broadcast read)
-    if (r >= B.rowCount[1]) r = y;                              // every row mass <= u
-    else {
-        r = r * 16 + chunk_count_le(rowL0 + r * 16, uRow);
-        if (r > y) r = y;
-    }
-    if (r >= y) r = y - 1;
+    int r = lds_count_le_pow2(rowL0, B.rowLog2, uRow);          // padding is +inf: never counted for finite u
+    if (r >= y) r = y - 1;                                      // also catches NaN (every compare true -> 2^log2n)
     const int row = rowIdx[r];
-    int c = chunk_count_le(colTop + row * 16, uCol);
+    int c = lds_count_le_pow2(colTop + row * 16, 4, uCol);     // which 16-chunk of this row's column CDF
     int col;
     if (c >= B.colCount[1]) {                                   // every entry of this row's CDF <= u: clamp to the last
         const int32_t *iline = reinterpret_cast<const int32_t *>(B.colPacked + (static_cast<size_t>(row) * B.colChunks + (x - 1) / 16) * 32 + 16);
@@ -83,12 +92,15 @@ __device__ __forceinline__ V2 bokeh_sample_lds(const BokehTables &B, const float
         int k = chunk_count_le(line, uCol);                     // one 64-byte global read; < 16 because the chunk max > u
         int e = c * 16 + k;
         if (e >= x) e = x - 1;
-        const float *line2 = B.colPacked + (static_cast<size_t>(row) * B.colChunks + (e >> 4)) * 32;
-        col = reinterpret_cast<const int32_t *>(line2 + 16)[e & 15];   // same 128-byte line: L1 hit
+        col = reinterpret_cast<const int32_t *>(line + 16)[e & 15];    // same 128-byte line: L1 hit
     }
     const float flippedRow = static_cast<float>(col - ((y - 1) / 2));
     const float flippedColumn = static_cast<float>(row - ((x - 1) / 2)) * -1.0f;
-    return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
+    if constexpr (EXACT_DIVIDE)
+        return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
+    else  // fast mode: wave-uniform reciprocals (exact when x, y are powers of two)
+        return V2{flippedRow * (2.0f * __builtin_amdgcn_rcpf(static_cast<float>(x))),
+                  flippedColumn * (2.0f * __builtin_amdgcn_rcpf(static_cast<float>(y)))};
 }
 
 }  // namespace zoic

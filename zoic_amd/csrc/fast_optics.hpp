@@ -23,13 +23,41 @@ __device__ __forceinline__ float frsq_fast(float x) { return __builtin_amdgcn_rs
 __device__ __forceinline__ float fast_sin_f32(float x) { return parabola_sin(wrap_to_pi(x)); }
 __device__ __forceinline__ float fast_cos_f32(float x) { return parabola_sin(wrap_to_pi(x + kPiOver2)); }
 
+__device__ __forceinline__ float frcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// concentricDiskSample (zoic.cpp:686-704) with one v_rcp_f32 instead of an IEEE divide; branch-free
 __device__ __forceinline__ V2 concentric_disk_f32(float ox, float oy)
 {
     const float a = 2.0f * ox - 1.0f, b = 2.0f * oy - 1.0f;
-    float r, phi;
-    if ((a * a) > (b * b)) { r = a; phi = 0.78539816339f * (b / a); }
-    else { r = b; phi = kPiOver2 - 0.78539816339f * (a / b); }
-    return V2{r * fast_cos_f32(phi), r * fast_sin_f32(phi)};
+    const bool wide = (a * a) > (b * b);
+    const float num = wide ? b : a, den = wide ? a : b;
+    const float q = 0.78539816339f * (num * frcp_fast(den));   // 0/0 -> NaN like the reference
+    const float phi = wide ? q : kPiOver2 - q;
+    return V2{den * fast_cos_f32(phi), den * fast_sin_f32(phi)};
+}
+
+// atan2 to ~2e-7 rad (the parabola sin/cos that consume it are 1e-3 approximations of sin/cos anyway, but they must
+// see the reference's angle): minimax odd polynomial on [0,1] + octant unfolding, one v_rcp_f32, no branches.
+__device__ __forceinline__ float atan2_f32(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * frcp_fast(mx);            // in [0,1]; 0/0 -> NaN -> handled below
+    const float s = t * t;
+    // atan(t)/t on [0,1], degree-7 in s (Abramowitz-Stegun style minimax, max error ~1e-7)
+    float p = -0.0040540580f;
+    p = p * s + 0.0218612288f;
+    p = p * s - 0.0559098861f;
+    p = p * s + 0.0964200441f;
+    p = p * s - 0.1390853351f;
+    p = p * s + 0.1994653599f;
+    p = p * s - 0.3332985605f;
+    p = p * s + 0.9999993329f;
+    float r = p * t;
+    r = (ay > ax) ? kPiOver2 - r : r;
+    r = (x < 0.0f) ? kPi - r : r;
+    r = (mx == 0.0f) ? 0.0f : r;                   // atan2(0,0) = 0
+    return copysignf(r, y);
 }
 
 __device__ __forceinline__ float uniform_f32(float v)
@@ -55,41 +83,96 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
 //   1 - cs2 = (1 - eta^2) + (eta/R)^2 thc^2,   TIR <=> 1 - cs2 < 0,
 //   u' = eta u + (eta cos(i) - sqrt(1 - cs2)) N      (|u'| = 1 again).
 // ~28 VALU + 2 v_sqrt_f32 per interface instead of ~52.
-__device__ __forceinline__ bool trace_lens_fast(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+//
+// One interface of the fast trace.  Returns 0 = passed, 1 = clipped (o, u untouched), 2 = total internal reflection
+// (o advanced, u untouched) -- the two partial states the reference can leave.
+__device__ __forceinline__ int fast_interface(const FastSurface &S, bool isStop, float userAperture2, V3 &o, V3 &u)
 {
-    const int n = T.lensCount;
+    const float Lz = S.center - o.z;
+    const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
+    const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
+    const float w = fabsf(S.radius2 - d2);                 // thc^2
+    const float thc = fsqrt_fast(w);
+    const float t = tca + thc * S.sign;
+    const V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
+    const float h2 = hit.x * hit.x + hit.y * hit.y;
+    const bool clipped = (d2 > S.radius2) | (h2 > S.housing2) | (isStop & (h2 > userAperture2));
+    if (clipped) return 1;
+    o = hit;
+    const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
+    if (oneMinusCs2 < 0.0f) return 2;                       // cs2 > 1 (only reachable when eta > 1)
+    const float k = thc * S.etaInvAbsR - fsqrt_fast(oneMinusCs2);
+    const float kr = k * S.invRadius;                       // k * N = kr * (c - hit)
+    u = V3{u.x * S.eta - hit.x * kr, u.y * S.eta - hit.y * kr, u.z * S.eta + (S.center - hit.z) * kr};
+    return 0;
+}
+
+// Rolled, branchy trace for any interface count.  It leaves exactly the partial state of the reference on every exit
+// path, so it is also what finishes rays that ran out of tries in the predicated kernel below.
+__device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+{
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
     V3 u{d.x * inv, d.y * inv, d.z * inv};
     bool ok = true, refracted = false;
-    // Every lane still in the loop is at the same surface, but the divergent exits hide that from the compiler, which
-    // would fetch the table per lane with vector loads and keep it in VGPRs.  readfirstlane pins the index and the
-    // table words to SGPRs: scalar loads, issued one iteration ahead of their use.
+    const int n = T.lensCount;
+    // Every lane still in the loop is at the same surface, but the divergent exits hide that from the compiler;
+    // readfirstlane pins the index and the table words to SGPRs (scalar loads, one iteration ahead).
     FastSurface Snext = T.fsurf[0];
     for (int i = 0;;) {
         const int iu = __builtin_amdgcn_readfirstlane(i);
         const FastSurface S = uniform_surface(Snext);
         Snext = T.fsurf[(iu + 1 < n) ? iu + 1 : iu];
+        const int r = fast_interface(S, iu == T.apertureElement, T.userAperture2, o, u);
+        if (r != 0) { if (r == 2) ++tirCount; ok = false; break; }
+        refracted = true;
+        if (++i == n) break;
+    }
+    if (refracted) d = u;
+    return ok;
+}
+
+// Predicated, fully unrolled trace for a lens with exactly NS interfaces: NO divergent control flow.  Every lane
+// evaluates every interface; a lane that is clipped or totally reflected only clears its bit in the `alive` mask
+// (v_cmp -> SGPR pair, s_andn2).  Dead lanes keep computing on garbage, which costs nothing: a wave issues each VALU
+// instruction once whatever its exec mask.  The rolled loop above spends ~33 scalar instructions per interface on
+// exec-mask bookkeeping and loop control next to 37 VALU, and the scalar unit became the limiter; here an interface
+// is ~31 VALU + ~6 SALU, and its table words are s_loads at fixed kernel-argument offsets.  A wave-uniform test
+// every second interface leaves the trace as soon as no lane is alive (heavily vignetted passes).
+// Returns alive; o/u are the exit point and unit direction for alive lanes (unspecified for dead ones -- rays that
+// finish dead get their reference partial state from trace_lens_fast_rolled).
+template <int NS>
+__device__ __forceinline__ bool trace_lens_fast_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+{
+    static_assert(NS > 0, "predicated trace needs a compile-time interface count");
+    const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
+    V3 u{d.x * inv, d.y * inv, d.z * inv};
+    bool alive = true, tirSeen = false;
+    bool anyAlive = true;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;   // wave-uniform early out, every 2nd interface
+        if (!anyAlive) continue;
+        const FastSurface &S = T.fsurf[i];
         const float Lz = S.center - o.z;
         const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
         const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
         const float w = fabsf(S.radius2 - d2);                 // thc^2
         const float thc = fsqrt_fast(w);
         const float t = tca + thc * S.sign;
-        const V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
-        const float h2 = hit.x * hit.x + hit.y * hit.y;
-        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2) | ((iu == T.apertureElement) & (h2 > T.userAperture2));
-        if (clipped) { ok = false; break; }
-        o = hit;
+        o = V3{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};    // hit point
+        const float h2 = o.x * o.x + o.y * o.y;
+        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2) | ((i == T.apertureElement) & (h2 > T.userAperture2));
         const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
-        if (oneMinusCs2 < 0.0f) { ++tirCount; ok = false; break; }   // cs2 > 1 (only reachable when eta > 1)
-        const float k = thc * S.etaInvAbsR - fsqrt_fast(oneMinusCs2);
-        const float kr = k * S.invRadius;                       // k * N = kr * (c - hit)
-        u = V3{u.x * S.eta - hit.x * kr, u.y * S.eta - hit.y * kr, u.z * S.eta + (S.center - hit.z) * kr};
-        refracted = true;
-        if (++i == n) break;
+        const bool tirHere = oneMinusCs2 < 0.0f;
+        tirSeen |= alive & !clipped & tirHere;                  // counted only by rays that reached the refraction
+        alive &= !clipped & !tirHere;
+        const float k = thc * S.etaInvAbsR - fsqrt_fast(fabsf(oneMinusCs2));
+        const float kr = k * S.invRadius;
+        u = V3{u.x * S.eta - o.x * kr, u.y * S.eta - o.y * kr, u.z * S.eta + (S.center - o.z) * kr};
     }
-    if (refracted) d = u;
-    return ok;
+    tirCount += tirSeen ? 1u : 0u;
+    d = u;
+    return alive;
 }
 
 }  // namespace zoic

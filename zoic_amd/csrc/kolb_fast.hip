@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlockF) void kolb_rays_fast_kernel(const KolbTable
             d = V3{rx - o.x, ry - o.y, T.dirZ};
         }
         int tries = 0;
-        while (!trace_lens_fast(T, o, d, tir) && tries <= kMaxTries) {
+        while (!trace_lens_fast_rolled(T, o, d, tir) && tries <= kMaxTries) {
             o = o0;
             const float u = rng_unit(xor128(rng));
             const float v = rng_unit(xor128(rng));

@@ -41,7 +41,7 @@ template <bool STRICT>
 __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v)
 {
     if (T.useImage) {
-        if (bokehLds) return bokeh_sample_lds(B, bokehLds, T.bokehW, T.bokehH, u, v);
+        if (bokehLds) return bokeh_sample_lds<STRICT>(B, bokehLds, T.bokehW, T.bokehH, u, v);
         return bokeh_sample_device(B, T.bokehW, T.bokehH, u, v);
     }
     if constexpr (STRICT) return concentric_disk(u, v);
@@ -50,7 +50,7 @@ __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables 
 
 extern __shared__ __align__(16) float zoicDynLds[];
 
-template <bool STRICT>
+template <bool STRICT, int NS>
 __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTable T, const BokehTables B,
                                                                    const float4 *__restrict__ samples,
                                                                    const uint4 *__restrict__ rngStates, uint64_t rayBase,
@@ -106,9 +106,7 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
             const float4 s = make_float4(__shfl(win.x, rank, 64), __shfl(win.y, rank, 64), __shfl(win.z, rank, 64),
                                          __shfl(win.w, rank, 64));  // (sx, sy, lensx, lensy)
             if (!active && rank < avail) {
-                idx = next + rank;
-                if (rngStates) { const uint4 r = rngStates[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
-                else rng = rng_for_ray(T.seed, rayBase + idx);
+                idx = next + rank;   // the retry stream is seeded lazily, at the ray's first retry (most rays never need it)
                 o0x = s.x * T.halfSensor;  // zoic.cpp:1853-1854
                 o0y = s.y * T.halfSensor;
                 u = s.z; v = s.w;
@@ -148,6 +146,10 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
         // ---- one try for every active lane ---------------------------------------------------------------------
         if (active) {
             if (!fresh) {                       // retry: new lens sample from the ray's own stream, zoic.cpp:1930
+                if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
+                    if (rngStates) { const uint4 r = rngStates[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+                    else rng = rng_for_ray(T.seed, rayBase + idx);
+                }
                 u = rng_unit(xor128(rng));
                 v = rng_unit(xor128(rng));
                 ++tries;
@@ -166,13 +168,24 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
                 d = V3{rx - o.x, ry - o.y, T.dirZ};
             }
             const uint32_t tirBefore = tir;
+            const V3 oStart = o, dStart = d;
             bool ok;
             if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
-            else ok = trace_lens_fast(T, o, d, tir);
+            else if constexpr (NS > 0) ok = trace_lens_fast_pred<NS>(T, o, d, tir);
+            else ok = trace_lens_fast_rolled(T, o, d, tir);
             if (!ok && fresh && dead && finiteSample) {
                 // 26 more identical failures: account for their TIR bumps, then finish the ray as the reference would
                 tir += (tir - tirBefore) * (static_cast<uint32_t>(kMaxTries) + 1u);
                 tries = static_cast<uint32_t>(kMaxTries) + 1u;
+            }
+            if constexpr (!STRICT && NS > 0) {
+                // the predicated trace does not keep the partial state of a failed ray; a ray that FINISHES failed
+                // (out of tries) gets it from the branchy trace, which stops at the failing interface
+                if (!ok && tries > static_cast<uint32_t>(kMaxTries)) {
+                    uint32_t ignored = 0;
+                    o = oStart; d = dStart;
+                    (void)trace_lens_fast_rolled(T, o, d, ignored);
+                }
             }
             fresh = false;
             if (ok || tries > static_cast<uint32_t>(kMaxTries)) {  // loop exit of zoic.cpp:1927
@@ -223,12 +236,20 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         // bokeh tables in LDS when the image is on and its LDS image fits comfortably (<= 40 KB keeps 4 workgroups per CU)
         const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
         const size_t ldsBytes = static_cast<size_t>(ldsWords) * sizeof(float);
-        if (fast)
-            hipLaunchKernelGGL(kolb_refill_kernel<false>, dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,
-                               rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords);
-        else
-            hipLaunchKernelGGL(kolb_refill_kernel<true>, dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,
-                               rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords);
+#define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
+    hipLaunchKernelGGL((kolb_refill_kernel<STRICT_, NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
+                       rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords)
+        if (!fast) ZOIC_LAUNCH_REFILL(true, 0);
+        else switch (table.lensCount) {  // unrolled instantiations for the interface counts of real prescriptions
+            case 7: ZOIC_LAUNCH_REFILL(false, 7); break;
+            case 8: ZOIC_LAUNCH_REFILL(false, 8); break;
+            case 9: ZOIC_LAUNCH_REFILL(false, 9); break;
+            case 10: ZOIC_LAUNCH_REFILL(false, 10); break;
+            case 11: ZOIC_LAUNCH_REFILL(false, 11); break;
+            case 12: ZOIC_LAUNCH_REFILL(false, 12); break;
+            default: ZOIC_LAUNCH_REFILL(false, 0); break;
+        }
+#undef ZOIC_LAUNCH_REFILL
         e = hipGetLastError();
         if (e != hipSuccess) return static_cast<int>(e);
     }

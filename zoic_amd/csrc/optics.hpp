@@ -211,8 +211,8 @@ ZOIC_HD bool lut_lookup(const KolbTable &T, float dist, float &maxScale, float &
         return true;
     }
     float lowerBound = static_cast<float>(low) * 0.125f;
-    float prev = static_cast<float>(low - 1) * 0.125f;
-    float percentage = (dist - lowerBound) / (prev - lowerBound);
+    // (dist - lowerBound) / (prev - lowerBound): the divisor is exactly -0.125, so the quotient is the exact product
+    float percentage = (dist - lowerBound) * -8.0f;
     float a = T.lutMaxScale[low], b = T.lutMaxScale[low - 1];
     maxScale = (a + percentage * (b - a)) * samplingErrorCorrection;     // linearInterpolate, zoic.cpp:655-657
     float ca = T.lutCentroidX[low], cb = T.lutCentroidX[low - 1];

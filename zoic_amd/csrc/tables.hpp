@@ -102,14 +102,15 @@ struct BokehTables {
     int32_t levels;                          // 0: pyramid not built (CDF longer than 4096) -> binary search
     // Two-level images (x, y <= 256): everything the row search needs plus the top level of every column pyramid is
     // copied into LDS once per workgroup (ldsImage, ldsWords dwords):
-    //   [ rowTop 16 f | rowL0 rowStride0 f | rowIndices rowStride0 i32 | colTop y*16 f ]
+    //   [ rowTop 16 f (unused) | rowL0 rowStride0 f | rowIndices rowStride0 i32 | colTop y*16 f ]
     // and level 0 of the column pyramids is packed with the pixel indices, one 128-byte line per 16-entry chunk:
     //   colPacked[(row*colChunks + chunk)*32 + k] = cdf (k < 16) | columnIndices - row*x as i32 (k >= 16)
     // so a lens sample costs 4 LDS round trips + 1 global line (+ an L1 hit) instead of 6 global round trips.
     const float *ldsImage;
     const float *colPacked;
     int32_t ldsWords;      // 0: not available
-    int32_t rowStride0;    // ceil16(y)
+    int32_t rowStride0;    // floats reserved for the row CDF in the LDS image: next power of two >= max(y,16), +inf padded
+    int32_t rowLog2;       // log2(rowStride0)
     int32_t colChunks;     // ceil(x/16)
 };
 
