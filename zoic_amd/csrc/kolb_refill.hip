@@ -50,6 +50,45 @@ __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables 
 
 extern __shared__ __align__(16) float zoicDynLds[];
 
+// STRICT arithmetic (optics.hpp trace_lens_strict, operation for operation) in the predicated, fully unrolled shape of
+// trace_lens_fast_pred: lanes that fail only clear their bit in `alive`; every surviving lane executes exactly the
+// reference's sequence of roundings, so alive lanes are bit-identical to the branchy version.  Rays that FINISH failed
+// get their partial state from trace_lens_strict.
+template <int NS>
+__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+{
+    static_assert(NS > 0, "predicated trace needs a compile-time interface count");
+    bool alive = true, tirSeen = false, anyAlive = true;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;
+        if (!anyAlive) continue;
+        const Surface &S = T.surf[i];
+        V3 u = normalize3(d);
+        V3 L{0.0f - o.x, 0.0f - o.y, S.center - o.z};
+        float tca = dot3(L, u);
+        float d2 = dot3(L, L) - (tca * tca);
+        float thc = sqrtf(fabsf(S.radius2 - d2));
+        float t = tca + thc * S.sign;
+        V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
+        float h2 = hit.x * hit.x + hit.y * hit.y;
+        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2) | ((i == T.apertureElement) & (h2 > T.userAperture2));
+        V3 nrm = normalize3(V3{0.0f - hit.x, 0.0f - hit.y, S.center - hit.z});
+        nrm = V3{nrm.x * S.sign, nrm.y * S.sign, nrm.z * S.sign};
+        o = hit;
+        V3 N = normalize3(nrm);
+        float c1 = -dot3(u, N);
+        float cs2 = static_cast<float>(static_cast<double>(S.eta * S.eta) * (1.0 - static_cast<double>(c1 * c1)));
+        const bool tirHere = (S.tirPossible != 0u) & (cs2 > 1.0f);
+        tirSeen |= alive & !clipped & tirHere;
+        alive &= !clipped & !tirHere;
+        float k = static_cast<float>(static_cast<double>(S.eta * c1) - sqrt(fabs(1.0 - static_cast<double>(cs2))));
+        d = V3{u.x * S.eta + N.x * k, u.y * S.eta + N.y * k, u.z * S.eta + N.z * k};
+    }
+    tirCount += tirSeen ? 1u : 0u;
+    return alive;
+}
+
 template <bool STRICT, int NS>
 __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTable T, const BokehTables B,
                                                                    const float4 *__restrict__ samples,
@@ -170,7 +209,8 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
             const uint32_t tirBefore = tir;
             const V3 oStart = o, dStart = d;
             bool ok;
-            if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
+            if constexpr (STRICT && NS > 0) ok = trace_lens_strict_pred<NS>(T, o, d, tir);
+            else if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
             else if constexpr (NS > 0) ok = trace_lens_fast_pred<NS>(T, o, d, tir);
             else ok = trace_lens_fast_rolled(T, o, d, tir);
             if (!ok && fresh && dead && finiteSample) {
@@ -178,13 +218,14 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTab
                 tir += (tir - tirBefore) * (static_cast<uint32_t>(kMaxTries) + 1u);
                 tries = static_cast<uint32_t>(kMaxTries) + 1u;
             }
-            if constexpr (!STRICT && NS > 0) {
+            if constexpr (NS > 0) {
                 // the predicated trace does not keep the partial state of a failed ray; a ray that FINISHES failed
                 // (out of tries) gets it from the branchy trace, which stops at the failing interface
                 if (!ok && tries > static_cast<uint32_t>(kMaxTries)) {
                     uint32_t ignored = 0;
                     o = oStart; d = dStart;
-                    (void)trace_lens_fast_rolled(T, o, d, ignored);
+                    if constexpr (STRICT) (void)trace_lens_strict(T, o, d, ignored);
+                    else (void)trace_lens_fast_rolled(T, o, d, ignored);
                 }
             }
             fresh = false;
@@ -239,7 +280,15 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
 #define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
     hipLaunchKernelGGL((kolb_refill_kernel<STRICT_, NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
                        rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords)
-        if (!fast) ZOIC_LAUNCH_REFILL(true, 0);
+        if (!fast) switch (table.lensCount) {
+            case 7: ZOIC_LAUNCH_REFILL(true, 7); break;
+            case 8: ZOIC_LAUNCH_REFILL(true, 8); break;
+            case 9: ZOIC_LAUNCH_REFILL(true, 9); break;
+            case 10: ZOIC_LAUNCH_REFILL(true, 10); break;
+            case 11: ZOIC_LAUNCH_REFILL(true, 11); break;
+            case 12: ZOIC_LAUNCH_REFILL(true, 12); break;
+            default: ZOIC_LAUNCH_REFILL(true, 0); break;
+        }
         else switch (table.lensCount) {  // unrolled instantiations for the interface counts of real prescriptions
             case 7: ZOIC_LAUNCH_REFILL(false, 7); break;
             case 8: ZOIC_LAUNCH_REFILL(false, 8); break;
