@@ -128,11 +128,17 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
 {
     uint32_t succ = 0, vign = 0;
     const bool useImage = T.useImage != 0;
+    __shared__ float4 stage[kBlock / 64][128];   // per-wave transpose buffer for the coalesced record store
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-        const float4 s = samples[i];
+    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * kBlock; tile < n; tile += stride) {  // whole waves stay together
+        const uint64_t waveBase = tile + wave * 64u;
+        if (waveBase >= n) continue;
+        const uint64_t i = waveBase + lane;
+        const bool have = i < n;
+        const float4 s = samples[have ? i : n - 1];
         Rng rng;
-        if (rngStates) { const uint4 r = rngStates[i]; rng = Rng{r.x, r.y, r.z, r.w}; }
+        if (rngStates) { const uint4 r = rngStates[have ? i : n - 1]; rng = Rng{r.x, r.y, r.z, r.w}; }
         else rng = rng_for_ray(T.seed, rayBase + i);
         const V3 p{s.x * T.tanFov, s.y * T.tanFov, 1.0f};
         const V3 originOriginal{0.0f, 0.0f, 0.0f};  // Arnold hands output.origin in as 0 (zoic.cpp:1777 reads it)
@@ -158,12 +164,14 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
                     ++tries;
                 }
             }
-            if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1824-1830
+            if (have) { if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ; }  // zoic.cpp:1824-1830
+            else if (tries > kMaxTries) w = 0.0f;
         }
         dir.z = dir.z * -1.0f;                     // zoic.cpp:1845
         if (T.exposureOn) w *= T.exposureMul;
-        store_ray_record(out, i, origin.x, origin.y, origin.z, dir.x, dir.y, dir.z, w,
-                         (tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1));
+        const uint64_t left = n - waveBase;
+        store_ray_records_wave(out, waveBase, lane, left < 64 ? static_cast<uint32_t>(left) : 64u, stage[wave], origin.x, origin.y,
+                               origin.z, dir.x, dir.y, dir.z, w, (tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1));
     }
     flush_counters(counters, succ, vign, 0u);
 }

@@ -33,6 +33,12 @@
 
 namespace zoic {
 
+// SGPR budget: a 256-lane workgroup is admitted per CU up to floor(800 / (ceil(sgpr/16)*16 + 16)) times
+// (MI355X_MICROARCH.md): 106 SGPRs -> 6 workgroups, <= 96 -> 7.  Capping at 94 measured +4.5 % on C3.
+#ifndef ZOIC_REFILL_ATTR
+#define ZOIC_REFILL_ATTR __attribute__((amdgpu_num_sgpr(94)))
+#endif
+
 constexpr int kRefillBlock = 256;
 constexpr int kWavesPerBlock = kRefillBlock / 64;
 constexpr uint32_t kChunkRays = 1024;  // samples a wave claims per atomic on the work cursor (16 passes of fresh work)
@@ -90,7 +96,7 @@ __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o
 }
 
 template <bool STRICT, int NS>
-__global__ __launch_bounds__(kRefillBlock) void kolb_refill_kernel(const KolbTable T, const BokehTables B,
+__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_kernel(const KolbTable T, const BokehTables B,
                                                                    const float4 *__restrict__ samples,
                                                                    const uint4 *__restrict__ rngStates, uint64_t rayBase,
                                                                    uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters,
