@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_RAY = 48  # 16 B sample in + one 32 B ray record out (28 B origin/dir/weight of SURVEY 8(d) + the 4 B flag word)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3
+VALU_PEAK_TWIPS = 0.95   # T wave64 VALU instr/s, whole chip, plain f32 ops at >= 4 waves/SIMD (tools/ubench/valu_rate.hip on MI355X)
 
 
 def parse_args():
@@ -174,13 +175,20 @@ def main():
         counters = cam.counters()
         done = counters["succesRays"] + counters["vignettedRays"]
         achieved = ALGO_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("%s_%s" % (args.config, args.precision), {}).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath) and not args.rays:
+            try:  # PMC numbers of the last committed rocprofv3 run of this (config, mode): bytes and VALU instructions
+                ent = json.load(open(tpath)).get("%s_%s" % (args.config, args.precision), {})
+                traffic = ent.get("hbm_bytes_per_launch")
+                if ent.get("lane_instr_per_ray"):
+                    rate = ent["lane_instr_per_ray"] / 64.0 * n / (kernel_ms * 1e-3) / 1e12
+                    valu = {"bound": "valu-issue", "achieved": round(rate, 4), "peak": VALU_PEAK_TWIPS, "unit": "T wave64-instr/s",
+                            "frac": round(rate / VALU_PEAK_TWIPS, 4), "lane_instr_per_ray": round(ent["lane_instr_per_ray"], 1),
+                            "lane_utilisation": round(ent.get("valu_thread_util", 0.0), 3),
+                            "note": "peak = measured plain-VALU issue rate (tools/ubench/valu_rate.hip); instruction count from profiles/ PMC"}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         line = {
             "metric": "camera rays/sec (Mrays/s), 4K x 16spp Kolb lens trace; ray-dir RMSE vs CPU ref",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,6 +205,8 @@ def main():
                          "note": "Kolb path is FP32-VALU bound (DESIGN.md); HBM fraction reported per the bench contract"},
             "zero_weight_frac": round(counters["vignettedRays"] / max(done, 1), 5),
         }
+        if valu:
+            line["valu_roofline"] = valu
         if not args.no_parity:
             line["parity"] = parity_probe(cam, args.config, args.precision)
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/oracle_vectors.npz: for each BASELINE config a few hundred seeded samples, their per-ray
+retry-stream states and the oracle's rays (planes + flags).  The oracle itself is pinned against the reference's
+src/draw.zoic (test_oracle_kat.py); these vectors freeze its per-sample output so that (a) any later edit of the
+oracle that changes a bit is caught on CPU, (b) the GPU parity tests also compare against committed data."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle
+from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_rng_states, synthetic_samples
+
+out = {}
+for cfg in ("C1", "C1ov", "C2", "C3", "C4", "C5"):
+    base_cfg = cfg[:2]
+    c = CONFIGS[base_cfg]
+    p = camera_params(base_cfg)
+    if cfg == "C1ov":
+        p["opticalVignettingDistance"] = 5.0
+    oc = oracle.OracleCamera()
+    if c["bokeh"]:
+        oc.set_bokeh_image(hexagon_bokeh())
+    oc.update(**p)
+    n_each = 96
+    # four frame positions: top-left corner region, off-centre, image centre, bottom-right region
+    bases = [(int(c["height"] * fy) * c["width"] + int(c["width"] * fx)) * c["spp"] + 7
+             for fy, fx in ((0.02, 0.0), (0.3, 0.62), (0.5, 0.5), (0.97, 0.9))]
+    s = np.concatenate([synthetic_samples(n_each, c["width"], c["height"], c["spp"], 1, b) for b in bases])
+    st = np.concatenate([ray_rng_states(n_each, 1, b) for b in bases])
+    r = oc.create_rays(s, rng_states=st)
+    out[cfg + "_samples"], out[cfg + "_states"], out[cfg + "_planes"], out[cfg + "_flags"] = s, st, r["planes"], r["flags"]
+    print(cfg, "zero_w", float((r["weight"] == 0).mean()), "retried", float((r["flags"] & 1).mean()))
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"), **out)
