@@ -112,15 +112,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libzoic_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)      # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1 or os.environ.get("ZOIC_FORCE_DIST"):   # ZOIC_FORCE_DIST: exercise the RCCL path on one GPU
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
 
     from zoic_amd.sharding import gather_rays, slab_for_rank
     cfg = CONFIGS[args.config]
@@ -148,7 +148,7 @@ def main():
         step()
     torch.cuda.synchronize()
     if dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -160,7 +160,7 @@ def main():
             gather_rays(out["rays"], n_total, dist, dst=0)
     torch.cuda.synchronize()
     if dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
@@ -213,7 +213,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
