@@ -96,7 +96,7 @@ __device__ __forceinline__ int fast_interface(const FastSurface &S, bool isStop,
     const float t = tca + thc * S.sign;
     const V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
     const float h2 = hit.x * hit.x + hit.y * hit.y;
-    const bool clipped = (d2 > S.radius2) | (h2 > S.housing2) | (isStop & (h2 > userAperture2));
+    const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
     if (clipped) return 1;
     o = hit;
     const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
@@ -161,7 +161,7 @@ __device__ __forceinline__ bool trace_lens_fast_pred(const KolbTable &T, V3 &o, 
         const float t = tca + thc * S.sign;
         o = V3{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};    // hit point
         const float h2 = o.x * o.x + o.y * o.y;
-        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2) | ((i == T.apertureElement) & (h2 > T.userAperture2));
+        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
         const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
         const bool tirHere = oneMinusCs2 < 0.0f;
         tirSeen |= alive & !clipped & tirHere;                  // counted only by rays that reached the refraction

@@ -41,6 +41,7 @@ namespace zoic {
 
 constexpr int kRefillBlock = 256;
 constexpr int kWavesPerBlock = kRefillBlock / 64;
+constexpr uint32_t kLutLdsWords = 2 * kLutEntries;  // (maxScale, centroid.x) pairs at the start of the dynamic LDS
 constexpr uint32_t kChunkRays = 1024;  // samples a wave claims per atomic on the work cursor (16 passes of fresh work)
 
 template <bool STRICT>
@@ -55,6 +56,25 @@ __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables 
 }
 
 extern __shared__ __align__(16) float zoicDynLds[];
+
+// lut_lookup (optics.hpp, zoic.cpp:1891-1911) reading the (maxScale, centroid.x) pairs from LDS: identical arithmetic
+__device__ __forceinline__ bool lut_lookup_lds(const float2 *lut, int lutSize, float dist, float &maxScale, float &translation)
+{
+    const float samplingErrorCorrection = 1.05f;
+    const float scaled = dist * 8.0f;
+    const int low = static_cast<int>(ceilf(scaled));
+    if (!(scaled <= static_cast<float>(lutSize - 1))) { maxScale = 0.0f; translation = 0.0f; return false; }
+    if (low <= 0) {
+        const float2 e = lut[0];
+        maxScale = e.x * samplingErrorCorrection; translation = e.y;
+        return true;
+    }
+    const float4 pr = *reinterpret_cast<const float4 *>(lut + (low - 1));   // entries low-1 (xy) and low (zw)
+    const float percentage = (dist - static_cast<float>(low) * 0.125f) * -8.0f;
+    maxScale = (pr.z + percentage * (pr.x - pr.z)) * samplingErrorCorrection;
+    translation = pr.w + percentage * (pr.y - pr.w);
+    return true;
+}
 
 // STRICT arithmetic (optics.hpp trace_lens_strict, operation for operation) in the predicated, fully unrolled shape of
 // trace_lens_fast_pred: lanes that fail only clear their bit in `alive`; every surviving lane executes exactly the
@@ -78,7 +98,7 @@ __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o
         float t = tca + thc * S.sign;
         V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
         float h2 = hit.x * hit.x + hit.y * hit.y;
-        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2) | ((i == T.apertureElement) & (h2 > T.userAperture2));
+        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
         V3 nrm = normalize3(V3{0.0f - hit.x, 0.0f - hit.y, S.center - hit.z});
         nrm = V3{nrm.x * S.sign, nrm.y * S.sign, nrm.z * S.sign};
         o = hit;
@@ -103,13 +123,19 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
                                                                    unsigned int *__restrict__ workCursor, uint32_t ldsWords)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    // bokeh row tables + column-pyramid tops -> LDS, once per workgroup (launch passes ldsWords*4 dynamic bytes or 0)
+    // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the
+    // two entries a sample interpolates -- then (ldsWords > 0) the bokeh row tables + column-pyramid tops
+    if (threadIdx.x < kLutEntries) {
+        zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
+        zoicDynLds[2 * threadIdx.x + 1] = T.lutCentroidX[threadIdx.x];
+    }
     const float *bokehLds = nullptr;
     if (ldsWords > 0) {
-        for (uint32_t i = threadIdx.x; i < ldsWords; i += kRefillBlock) zoicDynLds[i] = B.ldsImage[i];
-        __syncthreads();
-        bokehLds = zoicDynLds;
+        for (uint32_t i = threadIdx.x; i < ldsWords; i += kRefillBlock) zoicDynLds[kLutLdsWords + i] = B.ldsImage[i];
+        bokehLds = zoicDynLds + kLutLdsWords;
     }
+    __syncthreads();
+    const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
     // wave-uniform work window [next, end): a chunk of kChunkRays consecutive samples claimed from the global cursor
     uint32_t next = 0, end = 0;
     bool exhausted = false;
@@ -162,13 +188,13 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
                         const float theta = static_cast<float>(atan2(static_cast<double>(o0y), static_cast<double>(o0x)));
                         sn = fast_sin(theta);
                         cs = fast_cos(theta);
-                        lutMiss = lut_lookup(T, dist, maxScale, translation) ? 0u : 1u;
+                        lutMiss = lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation) ? 0u : 1u;
                     } else {
                         const float dist = fsqrt_fast(o0x * o0x + o0y * o0y);
                         const float theta = atan2f(o0y, o0x);
                         sn = fast_sin_f32(theta);
                         cs = fast_cos_f32(theta);
-                        lutMiss = lut_lookup(T, dist, maxScale, translation) ? 0u : 1u;
+                        lutMiss = lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation) ? 0u : 1u;
                     }
                     // Outside the image circle the LUT entries are all zero (zoic.cpp:1403-1404 never grown): every try
                     // then shoots lens = (0,0).  With o0x != 0 and o0y != 0 the direction (0 - o0x, 0 - o0y, dirZ) is
@@ -282,7 +308,7 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
         // bokeh tables in LDS when the image is on and its LDS image fits comfortably (<= 40 KB keeps 4 workgroups per CU)
         const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
-        const size_t ldsBytes = static_cast<size_t>(ldsWords) * sizeof(float);
+        const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float);
 #define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
     hipLaunchKernelGGL((kolb_refill_kernel<STRICT_, NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
                        rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords)

@@ -237,6 +237,9 @@ void LensSystem::fill_surfaces(KolbTable &t) const
         const double lim = half * half;
         float f = static_cast<float>(lim);
         if (static_cast<double>(f) > lim) f = std::nextafterf(f, -INFINITY);
+        // at the stop the reference also rejects h2 > userApertureRadius^2 (zoic.cpp:1115); two `>` tests against
+        // constants are one `>` test against the smaller constant
+        if (i == apertureElement && t.userAperture2 < f) f = t.userAperture2;
         s.housing2 = f;
         s.invRadius = 1.0f / r.radius;
         FastSurface &q = t.fsurf[i];

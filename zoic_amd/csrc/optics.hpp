@@ -139,7 +139,7 @@ ZOIC_HD bool trace_lens_strict(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCo
         V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
         // housing / user aperture clip, zoic.cpp:1111-1117
         float h2 = hit.x * hit.x + hit.y * hit.y;
-        if (h2 > S.housing2 || (i == T.apertureElement && h2 > T.userAperture2)) return false;
+        if (h2 > S.housing2) return false;  // housing2 of the stop already holds min(housing, user aperture)^2
         // intersectionNormal, zoic.cpp:999-1004
         V3 nrm = normalize3(V3{0.0f - hit.x, 0.0f - hit.y, S.center - hit.z});
         nrm = V3{nrm.x * S.sign, nrm.y * S.sign, nrm.z * S.sign};

@@ -30,7 +30,8 @@ struct Surface {
     float radius2;    // radius*radius in f32, as raySphereIntersection computes it (zoic.cpp:978)
     float sign;       // radius < 0 ? -1 : 1 (zoic.cpp:986, 1000)
     float eta;        // ior2 == 1.0 ? ior1 : ior1/ior2 (zoic.cpp:1013), ior2 = next surface's ior, 1.0 after the last
-    float housing2;   // largest f32 <= ((double)aperture*0.5)^2: `h2 > housing2` in f32 == the f64 compare of zoic.cpp:1114
+    float housing2;   // largest f32 <= ((double)aperture*0.5)^2: `h2 > housing2` in f32 == the f64 compare of zoic.cpp:1114;
+                      // for the stop: min(that, userApertureRadius^2) -- both clips of zoic.cpp:1114-1115 in one compare
     float invRadius;  // 1/radius (fast mode: unit normal = (c - hit) * invRadius)
     uint32_t tirPossible;  // ior1 > ior2 (zoic.cpp:1019)
 };
