@@ -136,12 +136,13 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
 // (v_cmp -> SGPR pair, s_andn2).  Dead lanes keep computing on garbage, which costs nothing: a wave issues each VALU
 // instruction once whatever its exec mask.  The rolled loop above spends ~33 scalar instructions per interface on
 // exec-mask bookkeeping and loop control next to 37 VALU, and the scalar unit became the limiter; here an interface
-// is ~31 VALU + ~6 SALU, and its table words are s_loads at fixed kernel-argument offsets.  A wave-uniform test
+// is ~31 VALU + ~6 SALU, and its table words are s_loads at fixed kernel-argument offsets (SGPR operands: staging
+// the table in LDS instead was measured 36 % slower on C4 -- VGPR copies, no scalar operands).  A wave-uniform test
 // every second interface leaves the trace as soon as no lane is alive (heavily vignetted passes).
 // Returns alive; o/u are the exit point and unit direction for alive lanes (unspecified for dead ones -- rays that
 // finish dead get their reference partial state from trace_lens_fast_rolled).
 template <int NS>
-__device__ __forceinline__ bool trace_lens_fast_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+__device__ __forceinline__ bool trace_lens_fast_pred(const FastSurface *__restrict__ surf, V3 &o, V3 &d, uint32_t &tirCount)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
@@ -152,7 +153,7 @@ __device__ __forceinline__ bool trace_lens_fast_pred(const KolbTable &T, V3 &o, 
     for (int i = 0; i < NS; ++i) {
         if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;   // wave-uniform early out, every 2nd interface
         if (!anyAlive) continue;
-        const FastSurface &S = T.fsurf[i];
+        const FastSurface S = surf[i];
         const float Lz = S.center - o.z;
         const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
         const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;

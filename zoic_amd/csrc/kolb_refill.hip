@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
             bool ok;
             if constexpr (STRICT && NS > 0) ok = trace_lens_strict_pred<NS>(T, o, d, tir);
             else if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
-            else if constexpr (NS > 0) ok = trace_lens_fast_pred<NS>(T, o, d, tir);
+            else if constexpr (NS > 0) ok = trace_lens_fast_pred<NS>(T.fsurf, o, d, tir);
             else ok = trace_lens_fast_rolled(T, o, d, tir);
             if (!ok && fresh && dead && finiteSample) {
                 // 26 more identical failures: account for their TIR bumps, then finish the ray as the reference would
