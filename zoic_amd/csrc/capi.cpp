@@ -27,6 +27,10 @@ namespace {
 
 thread_local std::string g_lastError;
 
+constexpr unsigned kWorkCursors = 64;   // launches of one camera that may be in flight at once
+constexpr unsigned kCursorStride = 32;  // 128 bytes apart: one cursor per cache line
+// a >2^31-sample call splits into several launches, each taking the next slot of the ring (kernels.hip)
+
 zoic_status fail(zoic_status s, const std::string &msg)
 {
     g_lastError = msg;
@@ -91,7 +95,8 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     DeviceBuffer<uint32_t> dRng;
     DeviceBuffer<uint8_t> dProbeOk;
     unsigned int *dProbeTir = nullptr;
-    unsigned int *dWorkCursor = nullptr;
+    unsigned int *dWorkCursor = nullptr;   // ring of kWorkCursors chunk cursors: launches in flight on different streams never share one
+    unsigned int nextCursor = 0;
 };
 
 namespace {
@@ -345,7 +350,7 @@ zoic_status zoic_camera_create(int device, zoic_camera **out)
     cam->lutOnHost = env && env[0] == '1';
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&cam->dCounters), sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipMemset(cam->dCounters, 0, sizeof(DeviceCounters));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), kWorkCursors * kCursorStride * sizeof(unsigned int));
     if (e != hipSuccess) {
         delete cam;
         return fail(ZOIC_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e));
@@ -417,11 +422,17 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
         cam->image.clear();
         if (p->useImage) {
             bool ok = false;
-            if (!cam->pendingPixels.empty()) {
-                ok = cam->image.build(cam->pendingPixels.data(), cam->pendW, cam->pendH, cam->pendC);
-            } else {
-                std::vector<float> px; int w = 0, h = 0, c = 0;
-                ok = read_pfm(bokehPath, px, w, h, c) && cam->image.build(px.data(), w, h, c);
+            std::vector<float> filePx;
+            const float *px = nullptr; int w = 0, h = 0, c = 0;
+            if (!cam->pendingPixels.empty()) { px = cam->pendingPixels.data(); w = cam->pendW; h = cam->pendH; c = cam->pendC; }
+            else if (read_pfm(bokehPath, filePx, w, h, c)) px = filePx.data();
+            if (px) {
+                // bokehProbability on the GPU (bokeh_cdf.hip) when the camera has one; ZOIC_CDF_HOST=1 keeps it on the host
+                const char *env = std::getenv("ZOIC_CDF_HOST");
+                int rc = -1;
+                if (onDevice && !(env && env[0] == '1')) rc = build_bokeh_cdf_device(px, w, h, c, cam->image);
+                if (rc > 0) return fail(ZOIC_ERR_HIP, std::string("bokeh CDF kernels: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+                ok = rc == 0 ? cam->image.valid() : cam->image.build(px, w, h, c);
             }
             if (!ok) status = fail(ZOIC_ERR_BOKEH_IMAGE, "[ZOIC] Couldn't open bokeh image!");
             else if (onDevice) { if (zoic_status s = upload_bokeh(cam)) return s; }
@@ -508,7 +519,8 @@ zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d
     switch (cam->params.p.lensModel) {
     case ZOIC_RAYTRACED:
         rc = launch_kolb_rays(cam->kolb, bokeh_tables(cam), d_samples, d_rng_states, ray_index_base, n, planes, cam->dCounters,
-                              cam->dWorkCursor, cam->precision == ZOIC_PRECISION_FAST, stream);
+                              cam->dWorkCursor + (cam->nextCursor++ % kWorkCursors) * kCursorStride,
+                              cam->precision == ZOIC_PRECISION_FAST, stream);
         break;
     case ZOIC_THINLENS:
         rc = launch_thin_rays(cam->thin, bokeh_tables(cam), d_samples, d_rng_states, ray_index_base, n, planes, cam->dCounters, stream);

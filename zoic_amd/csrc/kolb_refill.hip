@@ -296,7 +296,7 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;
     for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
         const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
-        hipError_t e = hipMemsetAsync(d_workCursor, 0, sizeof(unsigned int), st);
+        hipError_t e = hipMemsetAsync(d_workCursor, 0, sizeof(unsigned int), st);  // same stream as the kernel: ordered
         if (e != hipSuccess) return static_cast<int>(e);
         // persistent waves: enough workgroups to fill every wave slot of 256 CUs (8 x 256 lanes per CU); late or
         // surplus workgroups find the cursor exhausted and retire at once, so residency need not be known exactly

@@ -76,6 +76,10 @@ struct BokehCdf {
     void clear();
 };
 
+// bokeh_cdf.hip: the same tables built on the GPU (row-parallel sequential sums + LDS bitonic sorts), bit-identical.
+// 0 = ok, -1 = image not covered (dimension > 4096 or < 2: use BokehCdf::build), > 0 = hipError_t
+int build_bokeh_cdf_device(const float *pixels, int width, int height, int nchannels, BokehCdf &out);
+
 // minimal .pfm reader for bokehPath (the reference loads through Arnold's texture system, absent here)
 bool read_pfm(const std::string &path, std::vector<float> &pixels, int &w, int &h, int &nc);
 
