@@ -131,15 +131,21 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
     __shared__ float4 stage[kBlock / 64][128];   // per-wave transpose buffer for the coalesced record store
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    // software pipeline: the sample of the wave's NEXT tile is requested before the current one is evaluated
+    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kBlock + wave * 64u + lane;
+    float4 sNext = samples[first < n ? first : n - 1];
     for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * kBlock; tile < n; tile += stride) {  // whole waves stay together
         const uint64_t waveBase = tile + wave * 64u;
         if (waveBase >= n) continue;
         const uint64_t i = waveBase + lane;
         const bool have = i < n;
-        const float4 s = samples[have ? i : n - 1];
-        Rng rng;
-        if (rngStates) { const uint4 r = rngStates[have ? i : n - 1]; rng = Rng{r.x, r.y, r.z, r.w}; }
-        else rng = rng_for_ray(T.seed, rayBase + i);
+        const float4 s = sNext;
+        {
+            const uint64_t j = i + stride;
+            sNext = samples[j < n ? j : n - 1];
+        }
+        Rng rng{1u, 2u, 3u, 4u};
+        bool seeded = false;   // the private retry stream is seeded at the first retry only
         const V3 p{s.x * T.tanFov, s.y * T.tanFov, 1.0f};
         const V3 originOriginal{0.0f, 0.0f, 0.0f};  // Arnold hands output.origin in as 0 (zoic.cpp:1777 reads it)
         const V3 dir0 = normalize3(V3{p.x - originOriginal.x, p.y - originOriginal.y, p.z - originOriginal.z});
@@ -155,6 +161,11 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
             dir = normalize3(V3{fp.x - origin.x, fp.y - origin.y, fp.z - origin.z});
             if (T.ovDistance > 0.0f) {
                 while (!optical_vignet_pass(T, origin, dir) && tries <= kMaxTries) {  // zoic.cpp:1804-1819
+                    if (!seeded) {
+                        if (rngStates) { const uint4 r = rngStates[have ? i : n - 1]; rng = Rng{r.x, r.y, r.z, r.w}; }
+                        else rng = rng_for_ray(T.seed, rayBase + i);
+                        seeded = true;
+                    }
                     const float u = rng_unit(xor128(rng));
                     const float v = rng_unit(xor128(rng));
                     lens = sample_lens(useImage, B, T.bokehW, T.bokehH, u, v);
