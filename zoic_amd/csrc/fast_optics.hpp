@@ -107,6 +107,22 @@ __device__ __forceinline__ int fast_interface(const FastSurface &S, bool isStop,
     return 0;
 }
 
+// Does a ray clear interface 0 (first sphere hit + rear-element housing)?  Same arithmetic as the first half of
+// fast_interface; used by the kernel's candidate search so that tries dying at the rear element never pay for a trace.
+__device__ __forceinline__ bool interface0_clear_fast(const FastSurface &S, V3 o, V3 d)
+{
+    const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
+    const V3 u{d.x * inv, d.y * inv, d.z * inv};
+    const float Lz = S.center - o.z;
+    const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
+    const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
+    const float thc = fsqrt_fast(fabsf(S.radius2 - d2));
+    const float t = tca + thc * S.sign;
+    const float hx = o.x + u.x * t, hy = o.y + u.y * t;
+    const float h2 = hx * hx + hy * hy;
+    return !((d2 > S.radius2) | (h2 > S.housing2));
+}
+
 // Rolled, branchy trace for any interface count.  It leaves exactly the partial state of the reference on every exit
 // path, so it is also what finishes rays that ran out of tries in the predicated kernel below.
 __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
@@ -142,12 +158,12 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
 // Returns alive; o/u are the exit point and unit direction for alive lanes (unspecified for dead ones -- rays that
 // finish dead get their reference partial state from trace_lens_fast_rolled).
 template <int NS>
-__device__ __forceinline__ bool trace_lens_fast_pred(const FastSurface *__restrict__ surf, V3 &o, V3 &d, uint32_t &tirCount)
+__device__ __forceinline__ bool trace_lens_fast_pred(const FastSurface *__restrict__ surf, V3 &o, V3 &d, uint32_t &tirCount, bool alive0)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
     V3 u{d.x * inv, d.y * inv, d.z * inv};
-    bool alive = true, tirSeen = false;
+    bool alive = alive0, tirSeen = false;   // alive0: lanes without a candidate ride along dead
     bool anyAlive = true;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < NS; ++i) {

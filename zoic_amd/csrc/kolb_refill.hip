@@ -23,6 +23,8 @@
 // the scattered completion order causes no partial-line write-backs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_search.hpp"
 #include "fast_optics.hpp"
 #include "kernels.hpp"
@@ -42,7 +44,9 @@ namespace zoic {
 constexpr int kRefillBlock = 256;
 constexpr int kWavesPerBlock = kRefillBlock / 64;
 constexpr uint32_t kLutLdsWords = 2 * kLutEntries;  // (maxScale, centroid.x) pairs at the start of the dynamic LDS
-constexpr uint32_t kChunkRays = 1024;  // samples a wave claims per atomic on the work cursor (16 passes of fresh work)
+constexpr uint32_t kMinSearching = 16;  // the candidate search goes on while at least this many lanes of the wave are looking
+constexpr uint32_t kChunkRays = 1024;  // most samples a wave claims per atomic on the work cursor (16 passes of fresh work);
+                                       // small frames use smaller chunks so that every wave still gets >= 8 of them
 
 template <bool STRICT>
 __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v)
@@ -81,10 +85,10 @@ __device__ __forceinline__ bool lut_lookup_lds(const float2 *lut, int lutSize, f
 // reference's sequence of roundings, so alive lanes are bit-identical to the branchy version.  Rays that FINISH failed
 // get their partial state from trace_lens_strict.
 template <int NS>
-__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool alive0)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
-    bool alive = true, tirSeen = false, anyAlive = true;
+    bool alive = alive0, tirSeen = false, anyAlive = true;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
                                                                    const float4 *__restrict__ samples,
                                                                    const uint4 *__restrict__ rngStates, uint64_t rayBase,
                                                                    uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters,
-                                                                   unsigned int *__restrict__ workCursor, uint32_t ldsWords)
+                                                                   unsigned int *__restrict__ workCursor, uint32_t ldsWords, uint32_t chunkRays, uint32_t minSearching)
 {
     const uint32_t lane = threadIdx.x & 63u;
     // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the
@@ -159,10 +163,10 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
                 uint32_t c = 0;
                 if (lane == 0) c = atomicAdd(workCursor, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-                const uint64_t begin = static_cast<uint64_t>(c) * kChunkRays;
+                const uint64_t begin = static_cast<uint64_t>(c) * chunkRays;
                 if (begin >= n) { exhausted = true; break; }
                 next = static_cast<uint32_t>(begin);
-                end = (begin + kChunkRays < n) ? static_cast<uint32_t>(begin + kChunkRays) : n;
+                end = (begin + chunkRays < n) ? static_cast<uint32_t>(begin + chunkRays) : n;
             }
             if (winBase != next) {  // first use of a chunk: the window has to be fetched in line (once per kChunkRays)
                 const uint32_t wi = next + lane;
@@ -215,37 +219,70 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         if (__ballot(active) == 0ull) break;
 
         // ---- one try for every active lane ---------------------------------------------------------------------
-        if (active) {
-            if (!fresh) {                       // retry: new lens sample from the ray's own stream, zoic.cpp:1930
-                if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
-                    if (rngStates) { const uint4 r = rngStates[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
-                    else rng = rng_for_ray(T.seed, rayBase + idx);
+        // ---- candidate search: draw lens samples until one clears the rear element's housing -----------------------
+        // Most rejected tries die at interface 0 (rear-element housing / first sphere miss): 94 % of TESSAR retries, 91 %
+        // of wide-open PETZVAL retries, half of DOUBLE_GAUSS retries.  Testing interface 0 alone costs ~70 lane-
+        // instructions against ~900 for a whole try, so a lane keeps drawing (tries and RNG draws advance exactly as in
+        // the reference's loop, zoic.cpp:1927-1947) until its sample survives interface 0 or it runs out of tries; the
+        // full trace then runs once for the survivors.  The search loop is wave-uniform: it goes on while at least
+        // kMinSearching lanes are still looking, the rest simply carry their search into the next pass.
+        V3 o{o0x, o0y, T.originShift}, d{0.0f, 0.0f, 1.0f};
+        bool cand = false, finiteSample = true;
+        bool searching = active;
+        for (;;) {
+            if (searching) {
+                const bool first = fresh;
+                if (!first) {                       // retry: new lens sample from the ray's own stream, zoic.cpp:1930
+                    if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
+                        if (rngStates) { const uint4 r = rngStates[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+                        else rng = rng_for_ray(T.seed, rayBase + idx);
+                    }
+                    u = rng_unit(xor128(rng));
+                    v = rng_unit(xor128(rng));
+                    ++tries;
                 }
-                u = rng_unit(xor128(rng));
-                v = rng_unit(xor128(rng));
-                ++tries;
+                fresh = false;
+                V2 lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
+                // the dead-pixel shortcut needs a finite first sample (NaN*0 would differ from later tries)
+                finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
+                if (!T.useLUT) {                    // zoic.cpp:1873-1877 / 1882-1884
+                    d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+                } else {                            // zoic.cpp:1913-1924 / 1932-1943
+                    lens.x *= maxScale; lens.y *= maxScale;
+                    lens.x += translation;
+                    if (!first) lens.y += translation;  // retries translate BOTH components (zoic.cpp:1933)
+                    const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
+                    d = V3{rx - o.x, ry - o.y, T.dirZ};
+                }
+                bool pass0;
+                if constexpr (STRICT) pass0 = interface0_clear_strict(T, o, d);
+                else pass0 = interface0_clear_fast(T.fsurf[0], o, d);
+                if (pass0) { cand = true; searching = false; }
+                else {
+                    // a clip at interface 0 bumps no TIR counter and leaves (o, d) untouched: with the dead-pixel
+                    // shortcut all 27 tries are this one
+                    if (first && dead && finiteSample) tries = static_cast<uint32_t>(kMaxTries) + 1u;
+                    if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
+                }
             }
-            V2 lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
-            // the dead-pixel shortcut needs a finite first sample (NaN*0 would differ from later tries)
-            const bool finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
-            V3 o{o0x, o0y, T.originShift}, d;
-            if (!T.useLUT) {                    // zoic.cpp:1873-1877 / 1882-1884
-                d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
-            } else {                            // zoic.cpp:1913-1924 / 1932-1943
-                lens.x *= maxScale; lens.y *= maxScale;
-                lens.x += translation;
-                if (!fresh) lens.y += translation;  // retries translate BOTH components (zoic.cpp:1933)
-                const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
-                d = V3{rx - o.x, ry - o.y, T.dirZ};
-            }
+            const uint32_t looking = static_cast<uint32_t>(__popcll(__ballot(searching)));
+            if (looking < minSearching) break;
+        }
+
+        // ---- one full trace for every lane that holds a candidate -----------------------------------------------------
+        bool ok = false;
+        const V3 oStart = o, dStart = d;
+        const bool firstTry = tries == 0;
+        if (__ballot(cand) != 0ull) {
             const uint32_t tirBefore = tir;
-            const V3 oStart = o, dStart = d;
-            bool ok;
-            if constexpr (STRICT && NS > 0) ok = trace_lens_strict_pred<NS>(T, o, d, tir);
-            else if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
-            else if constexpr (NS > 0) ok = trace_lens_fast_pred<NS>(T.fsurf, o, d, tir);
-            else ok = trace_lens_fast_rolled(T, o, d, tir);
-            if (!ok && fresh && dead && finiteSample) {
+            if constexpr (NS > 0) {
+                if constexpr (STRICT) ok = trace_lens_strict_pred<NS>(T, o, d, tir, cand);
+                else ok = trace_lens_fast_pred<NS>(T.fsurf, o, d, tir, cand);
+            } else if (cand) {
+                if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
+                else ok = trace_lens_fast_rolled(T, o, d, tir);
+            }
+            if (cand && !ok && firstTry && dead && finiteSample) {
                 // 26 more identical failures: account for their TIR bumps, then finish the ray as the reference would
                 tir += (tir - tirBefore) * (static_cast<uint32_t>(kMaxTries) + 1u);
                 tries = static_cast<uint32_t>(kMaxTries) + 1u;
@@ -253,22 +290,25 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
             if constexpr (NS > 0) {
                 // the predicated trace does not keep the partial state of a failed ray; a ray that FINISHES failed
                 // (out of tries) gets it from the branchy trace, which stops at the failing interface
-                if (!ok && tries > static_cast<uint32_t>(kMaxTries)) {
+                if (cand && !ok && tries > static_cast<uint32_t>(kMaxTries)) {
                     uint32_t ignored = 0;
                     o = oStart; d = dStart;
                     if constexpr (STRICT) (void)trace_lens_strict(T, o, d, ignored);
                     else (void)trace_lens_fast_rolled(T, o, d, ignored);
                 }
             }
-            fresh = false;
-            if (ok || tries > static_cast<uint32_t>(kMaxTries)) {  // loop exit of zoic.cpp:1927
-                float w = 1.0f;
-                if (tries > static_cast<uint32_t>(kMaxTries)) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
-                if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
-                store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,  // zoic.cpp:1960-1961
-                                 (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6));
-                active = false;
-            }
+        }
+        // a ray is finished when a try got through, or when it is out of tries (loop exit of zoic.cpp:1927); a lane that
+        // ran out at interface 0 must hand out the untouched (o, d) of its last sample -- the reference's partial state
+        // (the predicated trace scribbles over the registers of lanes that ride along)
+        if (!cand) { o = oStart; d = dStart; }
+        if (active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries))) {
+            float w = 1.0f;
+            if (tries > static_cast<uint32_t>(kMaxTries)) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
+            if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
+            store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,  // zoic.cpp:1960-1961
+                             (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6));
+            active = false;
         }
     }
 
@@ -300,10 +340,16 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         if (e != hipSuccess) return static_cast<int>(e);
         // persistent waves: enough workgroups to fill every wave slot of 256 CUs (8 x 256 lanes per CU); late or
         // surplus workgroups find the cursor exhausted and retire at once, so residency need not be known exactly
-        const uint64_t chunks = (m + kChunkRays - 1) / kChunkRays;
-        const uint64_t wantBlocks = (chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+        const uint64_t tiles = (m + 63) / 64;
+        const uint64_t wantBlocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned grid = static_cast<unsigned>(wantBlocks < 2048 ? (wantBlocks ? wantBlocks : 1) : 2048);
+        // chunk = what one atomic claims: 1024 samples on big frames, down to one 64-sample tile on small ones, so that the
+        // dynamic cursor still has >= 8 chunks per wave to balance with
+        uint64_t chunk = m / (static_cast<uint64_t>(grid) * kWavesPerBlock * 8);
+        chunk = (chunk / 64) * 64;
+        const uint32_t chunkRays = static_cast<uint32_t>(chunk < 64 ? 64 : (chunk > kChunkRays ? kChunkRays : chunk));
         RayRecord *o = out + done;
+        static const uint32_t minSearching = [] { const char *e = std::getenv("ZOIC_MIN_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kMinSearching; }();
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
         const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
         // bokeh tables in LDS when the image is on and its LDS image fits comfortably (<= 40 KB keeps 4 workgroups per CU)
@@ -311,7 +357,7 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float);
 #define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
     hipLaunchKernelGGL((kolb_refill_kernel<STRICT_, NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
-                       rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords)
+                       rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords, chunkRays, minSearching)
         if (!fast) switch (table.lensCount) {
             case 7: ZOIC_LAUNCH_REFILL(true, 7); break;
             case 8: ZOIC_LAUNCH_REFILL(true, 8); break;

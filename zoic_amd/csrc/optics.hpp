@@ -158,6 +158,23 @@ ZOIC_HD bool trace_lens_strict(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCo
     return true;
 }
 
+// The interface-0 half of trace_lens_strict, operation for operation: does the ray hit the rear sphere and clear its
+// housing (zoic.cpp:1107-1117 for i == 0)?  A `false` here is exactly a `return false` of the first loop iteration.
+ZOIC_HD bool interface0_clear_strict(const KolbTable &T, V3 o, V3 d)
+{
+    const Surface S = T.surf[0];
+    V3 u = normalize3(d);
+    V3 L{0.0f - o.x, 0.0f - o.y, S.center - o.z};
+    float tca = dot3(L, u);
+    float d2 = dot3(L, L) - (tca * tca);
+    if (d2 > S.radius2) return false;
+    float thc = sqrtf(fabsf(S.radius2 - d2));
+    float t = tca + thc * S.sign;
+    V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
+    float h2 = hit.x * hit.x + hit.y * hit.y;
+    return !(h2 > S.housing2);
+}
+
 // ---- imageData::bokehSample, zoic.cpp:420-485 --------------------------------------------------------
 // std::upper_bound: index of the first element > v in a non-decreasing array
 ZOIC_HD int upper_bound_idx(const float *a, int n, float v)
