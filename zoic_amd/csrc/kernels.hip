@@ -22,6 +22,10 @@
 
 #pragma STDC FP_CONTRACT OFF
 
+#ifndef ZOIC_DEFAULT_KOLB_VARIANT
+#define ZOIC_DEFAULT_KOLB_VARIANT "refill"
+#endif
+
 namespace zoic {
 
 constexpr int kBlock = 256;
@@ -252,12 +256,14 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
                        uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                        bool fast, void *stream);
 
-// ZOIC_KOLB_VARIANT=simple selects the one-sample-per-lane kernels (A/B baseline); default: persistent lane refill
-static bool use_simple_variant()
+// ZOIC_KOLB_VARIANT = refill (persistent lane refill, default) | simple (one sample per lane, retry loop in the lane:
+// the A/B baseline of DESIGN.md's ladder).
+static const char *kolb_variant()
 {
     const char *e = std::getenv("ZOIC_KOLB_VARIANT");
-    return e && std::strcmp(e, "simple") == 0;
+    return e ? e : ZOIC_DEFAULT_KOLB_VARIANT;
 }
+static bool use_simple_variant() { return std::strcmp(kolb_variant(), "simple") == 0; }
 
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,

@@ -1,0 +1,93 @@
+// kolb_device.hpp -- device helpers shared by the persistent Kolb kernels (kolb_refill.hip, kolb_queue.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_search.hpp"
+#include "fast_optics.hpp"
+#include "kernels.hpp"
+#include "optics.hpp"
+#include "ray_store.hpp"
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace zoic {
+
+constexpr int kRefillBlock = 256;
+constexpr int kWavesPerBlock = kRefillBlock / 64;
+constexpr uint32_t kLutLdsWords = 2 * kLutEntries;  // (maxScale, centroid.x) pairs at the start of the dynamic LDS
+constexpr uint32_t kMinSearching = 16;  // the candidate search goes on while at least this many lanes of the wave are looking
+constexpr uint32_t kChunkRays = 1024;  // most samples a wave claims per atomic on the work cursor (16 passes of fresh work);
+                                       // small frames use smaller chunks so that every wave still gets >= 8 of them
+
+template <bool STRICT>
+__device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v)
+{
+    if (T.useImage) {
+        if (bokehLds) return bokeh_sample_lds<STRICT>(B, bokehLds, T.bokehW, T.bokehH, u, v);
+        return bokeh_sample_device(B, T.bokehW, T.bokehH, u, v);
+    }
+    if constexpr (STRICT) return concentric_disk(u, v);
+    else return concentric_disk_f32(u, v);
+}
+
+extern __shared__ __align__(16) float zoicDynLds[];
+
+// lut_lookup (optics.hpp, zoic.cpp:1891-1911) reading the (maxScale, centroid.x) pairs from LDS: identical arithmetic
+__device__ __forceinline__ bool lut_lookup_lds(const float2 *lut, int lutSize, float dist, float &maxScale, float &translation)
+{
+    const float samplingErrorCorrection = 1.05f;
+    const float scaled = dist * 8.0f;
+    const int low = static_cast<int>(ceilf(scaled));
+    if (!(scaled <= static_cast<float>(lutSize - 1))) { maxScale = 0.0f; translation = 0.0f; return false; }
+    if (low <= 0) {
+        const float2 e = lut[0];
+        maxScale = e.x * samplingErrorCorrection; translation = e.y;
+        return true;
+    }
+    const float4 pr = *reinterpret_cast<const float4 *>(lut + (low - 1));   // entries low-1 (xy) and low (zw)
+    const float percentage = (dist - static_cast<float>(low) * 0.125f) * -8.0f;
+    maxScale = (pr.z + percentage * (pr.x - pr.z)) * samplingErrorCorrection;
+    translation = pr.w + percentage * (pr.y - pr.w);
+    return true;
+}
+
+// STRICT arithmetic (optics.hpp trace_lens_strict, operation for operation) in the predicated, fully unrolled shape of
+// trace_lens_fast_pred: lanes that fail only clear their bit in `alive`; every surviving lane executes exactly the
+// reference's sequence of roundings, so alive lanes are bit-identical to the branchy version.  Rays that FINISH failed
+// get their partial state from trace_lens_strict.
+template <int NS>
+__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool alive0)
+{
+    static_assert(NS > 0, "predicated trace needs a compile-time interface count");
+    bool alive = alive0, tirSeen = false, anyAlive = true;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;
+        if (!anyAlive) continue;
+        const Surface &S = T.surf[i];
+        V3 u = normalize3(d);
+        V3 L{0.0f - o.x, 0.0f - o.y, S.center - o.z};
+        float tca = dot3(L, u);
+        float d2 = dot3(L, L) - (tca * tca);
+        float thc = sqrtf(fabsf(S.radius2 - d2));
+        float t = tca + thc * S.sign;
+        V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
+        float h2 = hit.x * hit.x + hit.y * hit.y;
+        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
+        V3 nrm = normalize3(V3{0.0f - hit.x, 0.0f - hit.y, S.center - hit.z});
+        nrm = V3{nrm.x * S.sign, nrm.y * S.sign, nrm.z * S.sign};
+        o = hit;
+        V3 N = normalize3(nrm);
+        float c1 = -dot3(u, N);
+        float cs2 = static_cast<float>(static_cast<double>(S.eta * S.eta) * (1.0 - static_cast<double>(c1 * c1)));
+        const bool tirHere = (S.tirPossible != 0u) & (cs2 > 1.0f);
+        tirSeen |= alive & !clipped & tirHere;
+        alive &= !clipped & !tirHere;
+        float k = static_cast<float>(static_cast<double>(S.eta * c1) - sqrt(fabs(1.0 - static_cast<double>(cs2))));
+        d = V3{u.x * S.eta + N.x * k, u.y * S.eta + N.y * k, u.z * S.eta + N.z * k};
+    }
+    tirCount += tirSeen ? 1u : 0u;
+    return alive;
+}
+
+}  // namespace zoic
