@@ -185,3 +185,30 @@ def test_bokeh_tie_rule_and_small_images(oracle_lib):
     pc.set_bokeh_image(np.ones((4, 4, 1), np.float32))
     with pytest.raises(ZoicError):
         pc.update(lensModel=THINLENS, useImage=True, bokehPath="mem:1ch")
+
+
+def _write_pfm(path, img, big_endian=False):
+    """img: (H, W, 3) float32, top row first; PFM stores rows bottom-to-top."""
+    h, w, _ = img.shape
+    data = img[::-1].astype(">f4" if big_endian else "<f4")
+    with open(path, "wb") as f:
+        f.write(("PF\n%d %d\n%s\n" % (w, h, "1.0" if big_endian else "-1.0")).encode())
+        f.write(data.tobytes())
+
+
+@pytest.mark.parametrize("big_endian", [False, True])
+def test_bokeh_path_pfm_file_equals_in_memory_pixels(tmp_path, big_endian):
+    """bokehPath pointing at a .pfm file (the library's stand-in for Arnold's texture loader, zoic.cpp:176-186) gives the
+    same CDF tables as handing over the pixels; a missing file is the reference's "Couldn't open bokeh image!" abort."""
+    rs = np.random.RandomState(5)
+    img = rs.rand(12, 20, 3).astype(np.float32)
+    p = str(tmp_path / "bokeh.pfm")
+    _write_pfm(p, img, big_endian)
+    a = ZoicCamera(device=-1).update(lensModel=THINLENS, useImage=True, bokehPath=p)
+    b = ZoicCamera(device=-1)
+    b.set_bokeh_image(img)
+    b.update(lensModel=THINLENS, useImage=True, bokehPath="mem:same")
+    ta, tb = a.bokeh_tables(), b.bokeh_tables()
+    assert (ta["x"], ta["y"]) == (20, 12)
+    for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+        assert np.array_equal(ta[k], tb[k]), k
