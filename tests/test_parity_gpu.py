@@ -311,3 +311,36 @@ def test_generic_interface_count_path(gpu, oracle_lib, text):
     dd = fast["dir"][:, live].astype(np.float64) - ref["dir"][:, live]
     assert float(np.sqrt((dd ** 2).sum(0).mean())) < DIR_RMSE_TOL
     assert 1.0 - float(same.mean()) < FLIP_TOL
+
+
+@pytest.mark.parametrize("shape,kind", [((256, 256), "falloff"), ((150, 200), "falloff"), ((64, 48), "spots"), ((256, 256), "spots")])
+def test_bokeh_cell_records_exact_on_dense_cells(gpu, oracle_lib, shape, kind):
+    """The cell-record sampler (one LDS record + one global record per lens sample) must return std::upper_bound's pixel
+    for every sample: images whose sorted CDFs crowd many entries into one cell (exponential falloff; a few bright spots on
+    a dim noisy background) exercise the exceptional path, and lens samples of exactly 0, 1.0, > 1, < 0 and NaN the
+    out-of-range path.  Strict mode, bit-exact against the oracle (zoic.cpp:420-485)."""
+    h, w = shape
+    rs = np.random.RandomState(11)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    if kind == "falloff":
+        lum = np.exp(-((xx - w / 2) ** 2 + (yy - h / 2) ** 2) / (0.02 * w * h)).astype(np.float32) + 1e-6 * rs.rand(h, w).astype(np.float32)
+    else:
+        lum = 1e-4 * rs.rand(h, w).astype(np.float32)
+        for _ in range(5):
+            lum[rs.randint(h), rs.randint(w)] = 1.0
+    img = np.repeat(lum[:, :, None], 3, axis=2).astype(np.float32)
+    p = dict(camera_params("C3"), bokehPath="mem:%s%dx%d" % (kind, w, h))
+    cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+    cam.set_bokeh_image(img); oc.set_bokeh_image(img)
+    cam.update(**p); oc.update(**p)
+    n = 1 << 16
+    s, base = slab("C3", n, 0.5)
+    s = s.copy()
+    s[:64, 2] = np.resize(np.array([0.0, 1.0, 1.5, -0.25, np.nan, 0.99999994, 1e-30, 0.5], np.float32), 64)
+    s[:64, 3] = np.resize(np.array([0.5, 0.0, 1.0, np.nan, 0.25, -1.0, 0.99999994, 2.0, 0.75], np.float32), 64)
+    got = cam.create_rays(s, ray_index_base=base)
+    ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=1, ray_index_base=base), threads=8)
+    assert np.array_equal(got["flags"], ref["flags"])
+    g, r = got["planes"], ref["planes"]
+    same = (bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))
+    assert same.all(), "%d rays differ" % (~same.all(0)).sum()

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzoic_amd.so")
+# ZOIC_AMD_LIB points at another build of the same library (A/B experiments, tools/); there is still no fallback
+LIB_PATH = os.environ.get("ZOIC_AMD_LIB") or os.path.join(HERE, "libzoic_amd.so")
 
 MAX_LENS_SURFACES = 32
 LUT_ENTRIES = 32

@@ -86,7 +86,8 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     KolbTable kolb{};
     ThinTable thin{};
     // device state
-    DeviceBuffer<float> dCdfRow, dCdfColumn, dPyramid, dBokehLds;
+    DeviceBuffer<float> dCdfRow, dCdfColumn, dPyramid;
+    DeviceBuffer<uint32_t> dBokehCells;
     DeviceBuffer<int32_t> dRowIdx, dColIdx;
     BokehTables bokehDev{};
     DeviceCounters *dCounters = nullptr;
@@ -234,40 +235,48 @@ zoic_status upload_bokeh(zoic_camera *cam)
         B.colCount[j] = cshape.count[j];
     }
     B.levels = levels;
-    // LDS image + packed column level 0 for two-level images (both dimensions <= 256)
-    if (levels == 2 && rp.levels <= 2 && cp.levels <= 2) {
-        int rowLog2 = 4;
-        while ((1 << rowLog2) < im.y) ++rowLog2;
-        const int rs0 = 1 << rowLog2, chunks = (im.x + 15) / 16;
-        const size_t ldsWords = 16 + static_cast<size_t>(rs0) * 2 + y * 16;
-        const size_t packedWords = y * static_cast<size_t>(chunks) * 32;
-        std::vector<float> img(ldsWords + packedWords);
-        float *p = img.data();
-        std::memcpy(p, rbase[1], 16 * sizeof(float));                               // rowTop (kept for layout stability)
-        for (int i = 0; i < rs0; ++i) p[16 + i] = i < im.y ? im.cdfRow[i] : INFINITY;  // rowL0, +inf padded to 2^k
-        int32_t *ri = reinterpret_cast<int32_t *>(p + 16 + rs0);
-        for (int i = 0; i < rs0; ++i) ri[i] = i < im.y ? im.rowIndices[i] : 0;      // rowIndices
-        for (size_t r = 0; r < y; ++r) std::memcpy(p + 16 + 2 * rs0 + r * 16, cbase[1] + r * cshape.stride[1], 16 * sizeof(float));  // colTop
-        float *pk = p + ldsWords;
-        const float inf = INFINITY;
-        for (size_t r = 0; r < y; ++r)
-            for (int c = 0; c < chunks; ++c) {
-                float *line = pk + (r * chunks + c) * 32;
-                int32_t *iline = reinterpret_cast<int32_t *>(line + 16);
-                for (int k = 0; k < 16; ++k) {
-                    const int e = c * 16 + k;
-                    line[k] = e < im.x ? im.cdfColumn[r * im.x + e] : inf;
-                    iline[k] = e < im.x ? im.columnIndices[r * im.x + e] - static_cast<int32_t>(r * im.x) : 0;
+    // cell records (tables.hpp) for images up to 256 x 256 with non-decreasing CDFs
+    if (im.x <= 256 && im.y <= 256) {
+        const auto monotone = [](const float *a, int n) {
+            for (int i = 0; i < n; ++i) if (!(a[i] == a[i]) || (i > 0 && a[i] < a[i - 1])) return false;
+            return true;
+        };
+        bool ok = monotone(im.cdfRow.data(), im.y);
+        for (size_t r = 0; ok && r < y; ++r) ok = monotone(im.cdfColumn.data() + r * im.x, im.x);
+        if (ok) {
+            const auto cellCount = [](int n) { int g = 16; while (g < n) g <<= 1; return g; };
+            const int gRow = cellCount(im.y), gCol = cellCount(im.x);
+            std::vector<uint32_t> cells((static_cast<size_t>(gRow) + y * static_cast<size_t>(gCol)) * 4);
+            // records of one CDF: cdf[n] non-decreasing, idx[n] pixel indices relative to `idxBase` (each < 256)
+            const auto fill = [](const float *cdf, const int32_t *idx, int32_t idxBase, int n, int g, uint32_t *out) {
+                for (int c = 0; c < g; ++c) {
+                    const float lower = static_cast<float>(c) / static_cast<float>(g), upper = static_cast<float>(c + 1) / static_cast<float>(g);
+                    const int lo = static_cast<int>(std::upper_bound(cdf, cdf + n, lower) - cdf);   // #{cdf <= lower}
+                    const int hi = static_cast<int>(std::lower_bound(cdf, cdf + n, upper) - cdf);   // #{cdf <  upper}
+                    const float inf = INFINITY;
+                    const float a = lo < n ? cdf[lo] : inf, b = lo + 1 < n ? cdf[lo + 1] : inf;
+                    uint32_t packed = (hi - lo > 2) ? (1u << 24) : 0u;
+                    for (int k = 0; k < 3; ++k)
+                        packed |= static_cast<uint32_t>((idx[std::min(lo + k, n - 1)] - idxBase) & 0xff) << (8 * k);
+                    uint32_t *rec = out + static_cast<size_t>(c) * 4;
+                    std::memcpy(rec + 0, &a, 4);
+                    std::memcpy(rec + 1, &b, 4);
+                    rec[2] = packed;
+                    rec[3] = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
                 }
-            }
-        ZOIC_HIP(cam->dBokehLds.reserve(img.size()));
-        ZOIC_HIP(hipMemcpy(cam->dBokehLds.ptr, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
-        B.ldsImage = cam->dBokehLds.ptr;
-        B.colPacked = cam->dBokehLds.ptr + ldsWords;
-        B.ldsWords = static_cast<int32_t>(ldsWords);
-        B.rowStride0 = rs0;
-        B.rowLog2 = rowLog2;
-        B.colChunks = chunks;
+            };
+            fill(im.cdfRow.data(), im.rowIndices.data(), 0, im.y, gRow, cells.data());
+            for (size_t r = 0; r < y; ++r)
+                fill(im.cdfColumn.data() + r * im.x, im.columnIndices.data() + r * im.x, static_cast<int32_t>(r * im.x), im.x, gCol,
+                     cells.data() + (static_cast<size_t>(gRow) + r * gCol) * 4);
+            ZOIC_HIP(cam->dBokehCells.reserve(cells.size()));
+            ZOIC_HIP(hipMemcpy(cam->dBokehCells.ptr, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            B.rowCells = cam->dBokehCells.ptr;
+            B.colCells = cam->dBokehCells.ptr + static_cast<size_t>(gRow) * 4;
+            B.ldsWords = gRow * 4;
+            B.rowCellCount = gRow;
+            B.colCellCount = gCol;
+        }
     }
     return ZOIC_OK;
 }
@@ -364,7 +373,7 @@ void zoic_camera_destroy(zoic_camera *cam)
     if (!cam) return;
     if (cam->device == ZOIC_DEVICE_NONE) { delete cam; return; }
     (void)hipSetDevice(cam->device);
-    cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release(); cam->dBokehLds.release();
+    cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release(); cam->dBokehCells.release();
     cam->dSamples.release(); cam->dRays.release(); cam->dInputs7.release(); cam->dRng.release();
     cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release();
     if (cam->dProbeTir) (void)hipFree(cam->dProbeTir);

@@ -58,44 +58,62 @@ __device__ __forceinline__ V2 bokeh_sample_device(const BokehTables &B, int x, i
     return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
 }
 
-// Number of entries <= v in a non-decreasing LDS array of 2^log2n floats (+inf padded): the classic branch-free
-// descent, one ds_read_b32 + compare + select per level with a wave-uniform step.  == std::upper_bound index.
-// The kernels are VALU-issue bound, so 3 VALU per level beats the 32 compares+adds of counting a 16-chunk.
-__device__ __forceinline__ int lds_count_le_pow2(const float *a, int log2n, float v)
+// One CDF resolved through its cell record (tables.hpp).  Returns the pixel index; identical to
+// indices[min(upper_bound(cdf, u), n-1)] for every u (NaN, negative and >= 1 samples take the exceptional path).
+struct CellLookup {
+    int index;      // pixel index when !exceptional
+    bool exceptional;
+    int lo, hi;     // upper_bound lies in [lo, hi] (exceptional path)
+};
+
+__device__ __forceinline__ int cell_of(float u, int cellCount, bool &inRange)
 {
-    int pos = 0;
-    for (int step = 1 << log2n; step > 0; step >>= 1) {
-        const int t = pos + step;
-        if (t <= (1 << log2n) && !(v < a[t - 1])) pos = t;
-    }
-    return pos;
+    inRange = (u >= 0.0f) & (u < 1.0f);
+    return inRange ? static_cast<int>(u * static_cast<float>(cellCount)) : 0;   // exact: cellCount is a power of two
 }
 
-// Lens sample with the row tables and the column pyramid tops resident in LDS (`lds` = the workgroup's copy of
-// BokehTables::ldsImage).  Identical indices to bokeh_sample_device / std::upper_bound.
-template <bool EXACT_DIVIDE>
-__device__ __forceinline__ V2 bokeh_sample_lds(const BokehTables &B, const float *lds, int x, int y, float uRow, float uCol)
+__device__ __forceinline__ CellLookup cell_resolve(const uint4 rec, float u, bool inRange, int n)
 {
-    const float *rowL0 = lds + 16;
-    const int32_t *rowIdx = reinterpret_cast<const int32_t *>(lds + 16 + B.rowStride0);
-    const float *colTop = lds + 16 + 2 * B.rowStride0;
-    int r = lds_count_le_pow2(rowL0, B.rowLog2, uRow);          // padding is +inf: never counted for finite u
-    if (r >= y) r = y - 1;                                      // also catches NaN (every compare true -> 2^log2n)
-    const int row = rowIdx[r];
-    int c = lds_count_le_pow2(colTop + row * 16, 4, uCol);     // which 16-chunk of this row's column CDF
-    int col;
-    if (c >= B.colCount[1]) {                                   // every entry of this row's CDF <= u: clamp to the last
-        const int32_t *iline = reinterpret_cast<const int32_t *>(B.colPacked + (static_cast<size_t>(row) * B.colChunks + (x - 1) / 16) * 32 + 16);
-        col = iline[(x - 1) & 15];
-    } else {
-        const float *line = B.colPacked + (static_cast<size_t>(row) * B.colChunks + c) * 32;
-        int k = chunk_count_le(line, uCol);                     // one 64-byte global read; < 16 because the chunk max > u
-        int e = c * 16 + k;
-        if (e >= x) e = x - 1;
-        col = reinterpret_cast<const int32_t *>(line + 16)[e & 15];    // same 128-byte line: L1 hit
+    const float a = __builtin_bit_cast(float, rec.x), b = __builtin_bit_cast(float, rec.y);
+    const int k = (!(u < a) ? 1 : 0) + (!(u < b) ? 1 : 0);
+    CellLookup r;
+    r.index = static_cast<int>((rec.z >> (8 * k)) & 0xffu);
+    r.exceptional = ((rec.z >> 24) != 0u) | !inRange;
+    r.lo = inRange ? static_cast<int>(rec.w & 0xffffu) : 0;
+    r.hi = inRange ? static_cast<int>(rec.w >> 16) : n;
+    return r;
+}
+
+// Lens sample through the cell records: `ldsRowCells` = the workgroup's LDS copy of BokehTables::rowCells.
+// Identical indices to bokeh_sample / std::upper_bound (zoic.cpp:420-485).
+template <bool EXACT_DIVIDE>
+__device__ __forceinline__ V2 bokeh_sample_cells(const BokehTables &B, const float *ldsRowCells, int x, int y, float uRow, float uCol)
+{
+    bool inR, inC;
+    const int gr = cell_of(uRow, B.rowCellCount, inR);
+    const int gc = cell_of(uCol, B.colCellCount, inC);
+    const CellLookup R = cell_resolve(reinterpret_cast<const uint4 *>(ldsRowCells)[gr], uRow, inR, y);
+    int row = R.index;
+    if (__ballot(R.exceptional) != 0ull) {          // rare, wave-uniform: dense cell or a sample outside [0,1)
+        if (R.exceptional) {
+            int r = R.lo + upper_bound_idx(B.cdfRow + R.lo, R.hi - R.lo, uRow);
+            if (r >= y) r = y - 1;
+            row = B.rowIndices[r];
+        }
     }
-    const float flippedRow = static_cast<float>(col - ((y - 1) / 2));
-    const float flippedColumn = static_cast<float>(row - ((x - 1) / 2)) * -1.0f;
+    const uint4 crec = reinterpret_cast<const uint4 *>(B.colCells)[static_cast<uint32_t>(row) * static_cast<uint32_t>(B.colCellCount) + static_cast<uint32_t>(gc)];
+    const CellLookup Cc = cell_resolve(crec, uCol, inC, x);
+    int col = Cc.index;
+    if (__ballot(Cc.exceptional) != 0ull) {
+        if (Cc.exceptional) {
+            const int start = row * x;
+            int c = Cc.lo + upper_bound_idx(B.cdfColumn + start + Cc.lo, Cc.hi - Cc.lo, uCol);
+            if (c >= x) c = x - 1;
+            col = B.columnIndices[start + c] - start;
+        }
+    }
+    const float flippedRow = static_cast<float>(col - ((y - 1) / 2));             // zoic.cpp:466,479 (x/y swapped)
+    const float flippedColumn = static_cast<float>(row - ((x - 1) / 2)) * -1.0f;  // zoic.cpp:441,480
     if constexpr (EXACT_DIVIDE)
         return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
     else  // fast mode: wave-uniform reciprocals (exact when x, y are powers of two)

@@ -23,7 +23,7 @@ template <bool STRICT>
 __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v)
 {
     if (T.useImage) {
-        if (bokehLds) return bokeh_sample_lds<STRICT>(B, bokehLds, T.bokehW, T.bokehH, u, v);
+        if (bokehLds) return bokeh_sample_cells<STRICT>(B, bokehLds, T.bokehW, T.bokehH, u, v);
         return bokeh_sample_device(B, T.bokehW, T.bokehH, u, v);
     }
     if constexpr (STRICT) return concentric_disk(u, v);

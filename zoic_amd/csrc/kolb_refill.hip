@@ -37,6 +37,19 @@ namespace zoic {
 #define ZOIC_REFILL_ATTR __attribute__((amdgpu_num_sgpr(94)))
 #endif
 
+// Debug build only (-DZOIC_REGION_TIMERS, tools/region_times.py): per-wave s_memtime cycles spent in each region of the
+// pass loop, summed over all waves.  Not part of the product build.
+#ifdef ZOIC_REGION_TIMERS
+__device__ unsigned long long g_regionCycles[8];
+#define ZOIC_RT_DECL unsigned long long rtAcc[5] = {0, 0, 0, 0, 0}, rtLast = __builtin_readcyclecounter();
+#define ZOIC_RT_MARK(R) { const unsigned long long rtNow = __builtin_readcyclecounter(); rtAcc[R] += rtNow - rtLast; rtLast = rtNow; }
+#define ZOIC_RT_FLUSH if (lane == 0) { for (int r = 0; r < 5; ++r) atomicAdd(&g_regionCycles[r], rtAcc[r]); atomicAdd(&g_regionCycles[7], 1ull); }
+#else
+#define ZOIC_RT_DECL
+#define ZOIC_RT_MARK(R)
+#define ZOIC_RT_FLUSH
+#endif
+
 template <bool STRICT, int NS>
 __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_kernel(const KolbTable T, const BokehTables B,
                                                                    const float4 *__restrict__ samples,
@@ -46,14 +59,14 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
 {
     const uint32_t lane = threadIdx.x & 63u;
     // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the
-    // two entries a sample interpolates -- then (ldsWords > 0) the bokeh row tables + column-pyramid tops
+    // two entries a sample interpolates -- then (ldsWords > 0) the bokeh row cell records (tables.hpp)
     if (threadIdx.x < kLutEntries) {
         zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
         zoicDynLds[2 * threadIdx.x + 1] = T.lutCentroidX[threadIdx.x];
     }
     const float *bokehLds = nullptr;
     if (ldsWords > 0) {
-        for (uint32_t i = threadIdx.x; i < ldsWords; i += kRefillBlock) zoicDynLds[kLutLdsWords + i] = B.ldsImage[i];
+        for (uint32_t i = threadIdx.x; i < ldsWords; i += kRefillBlock) zoicDynLds[kLutLdsWords + i] = __builtin_bit_cast(float, B.rowCells[i]);
         bokehLds = zoicDynLds + kLutLdsWords;
     }
     __syncthreads();
@@ -72,8 +85,10 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
     float o0x = 0, o0y = 0, maxScale = 0, translation = 0, sn = 0, cs = 1, u = 0, v = 0;
     Rng rng{1, 2, 3, 4};
     uint32_t succ = 0, vign = 0, tir = 0;
+    ZOIC_RT_DECL
 
     for (;;) {
+        ZOIC_RT_MARK(4)
         // ---- refill the free lanes from the work window (ballot + prefix sum) ---------------------------------
         unsigned long long freeMask = __ballot(!active);
         while (freeMask != 0ull && !exhausted) {
@@ -135,6 +150,7 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
             freeMask = __ballot(!active);
         }
         if (__ballot(active) == 0ull) break;
+        ZOIC_RT_MARK(0)
 
         // ---- one try for every active lane ---------------------------------------------------------------------
         // ---- candidate search: draw lens samples until one clears the rear element's housing -----------------------
@@ -161,6 +177,9 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
                 }
                 fresh = false;
                 V2 lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
+#ifdef ZOIC_EXP_DOUBLE_SAMPLE
+                { const V2 l2 = lens_sample<STRICT>(T, B, bokehLds, u + lens.x * 0.0f, v + lens.y * 0.0f); lens.x += l2.x * 0.0f; lens.y += l2.y * 0.0f; }
+#endif
                 // the dead-pixel shortcut needs a finite first sample (NaN*0 would differ from later tries)
                 finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
                 if (!T.useLUT) {                    // zoic.cpp:1873-1877 / 1882-1884
@@ -175,6 +194,9 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
                 bool pass0;
                 if constexpr (STRICT) pass0 = interface0_clear_strict(T, o, d);
                 else pass0 = interface0_clear_fast(T.fsurf[0], o, d);
+#ifdef ZOIC_EXP_DOUBLE_PRETEST
+                if constexpr (!STRICT) { V3 d2 = d; d2.x += pass0 ? 0.0f : 1.0e-30f; pass0 = pass0 & interface0_clear_fast(T.fsurf[0], o, d2); }
+#endif
                 if (pass0) { cand = true; searching = false; }
                 else {
                     // a clip at interface 0 bumps no TIR counter and leaves (o, d) untouched: with the dead-pixel
@@ -187,6 +209,7 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
             if (looking < minSearching) break;
         }
 
+        ZOIC_RT_MARK(1)
         // ---- one full trace for every lane that holds a candidate -----------------------------------------------------
         bool ok = false;
         const V3 oStart = o, dStart = d;
@@ -196,6 +219,9 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
             if constexpr (NS > 0) {
                 if constexpr (STRICT) ok = trace_lens_strict_pred<NS>(T, o, d, tir, cand);
                 else ok = trace_lens_fast_pred<NS>(T.fsurf, o, d, tir, cand);
+#ifdef ZOIC_EXP_DOUBLE_TRACE
+                if constexpr (!STRICT) { V3 o2 = oStart, d2 = dStart; uint32_t t2 = 0; o2.x += o.x * 0.0f; const bool ok2 = trace_lens_fast_pred<NS>(T.fsurf, o2, d2, t2, cand); o.x += o2.x * 0.0f; ok = ok & (ok2 | !ok); }
+#endif
             } else if (cand) {
                 if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
                 else ok = trace_lens_fast_rolled(T, o, d, tir);
@@ -219,6 +245,7 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         // a ray is finished when a try got through, or when it is out of tries (loop exit of zoic.cpp:1927); a lane that
         // ran out at interface 0 must hand out the untouched (o, d) of its last sample -- the reference's partial state
         // (the predicated trace scribbles over the registers of lanes that ride along)
+        ZOIC_RT_MARK(2)
         if (!cand) { o = oStart; d = dStart; }
         if (active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries))) {
             float w = 1.0f;
@@ -230,6 +257,7 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         }
     }
 
+    ZOIC_RT_FLUSH
     // ---- counters: wave reduction, one atomic per counter per wave ---------------------------------------------
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -272,7 +300,9 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
         // bokeh tables in LDS when the image is on and its LDS image fits comfortably (<= 40 KB keeps 4 workgroups per CU)
         const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
-        const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float);
+        // ZOIC_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the workgroups a CU admits
+        static const size_t ldsPad = [] { const char *e = std::getenv("ZOIC_LDS_PAD"); return e ? static_cast<size_t>(std::atol(e)) : size_t(0); }();
+        const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + ldsPad;
 #define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
     hipLaunchKernelGGL((kolb_refill_kernel<STRICT_, NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
                        rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords, chunkRays, minSearching)
@@ -302,3 +332,15 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
 }
 
 }  // namespace zoic
+
+#ifdef ZOIC_REGION_TIMERS
+extern "C" int zoic_debug_region_cycles(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(zoic::g_regionCycles), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(zoic::g_regionCycles), z, sizeof(z));
+    }
+    return static_cast<int>(e);
+}
+#endif

@@ -101,18 +101,22 @@ struct BokehTables {
     int32_t rowCount[kBokehMaxLevels];       // valid entries per level of the row pyramid
     int32_t colCount[kBokehMaxLevels];       // valid entries per level of one column pyramid row
     int32_t levels;                          // 0: pyramid not built (CDF longer than 4096) -> binary search
-    // Two-level images (x, y <= 256): everything the row search needs plus the top level of every column pyramid is
-    // copied into LDS once per workgroup (ldsImage, ldsWords dwords):
-    //   [ rowTop 16 f (unused) | rowL0 rowStride0 f | rowIndices rowStride0 i32 | colTop y*16 f ]
-    // and level 0 of the column pyramids is packed with the pixel indices, one 128-byte line per 16-entry chunk:
-    //   colPacked[(row*colChunks + chunk)*32 + k] = cdf (k < 16) | columnIndices - row*x as i32 (k >= 16)
-    // so a lens sample costs 4 LDS round trips + 1 global line (+ an L1 hit) instead of 6 global round trips.
-    const float *ldsImage;
-    const float *colPacked;
-    int32_t ldsWords;      // 0: not available
-    int32_t rowStride0;    // floats reserved for the row CDF in the LDS image: next power of two >= max(y,16), +inf padded
-    int32_t rowLog2;       // log2(rowStride0)
-    int32_t colChunks;     // ceil(x/16)
+    // Cell records (x, y <= 256; built when both CDFs are non-decreasing): the unit interval of the sample is cut into
+    // G = 2^k >= n cells; for cell g = floor(u*G) (exact: G is a power of two) the record holds everything
+    // std::upper_bound needs when at most two CDF entries fall inside the cell:
+    //   .x = cdf[lo] as bits, .y = cdf[lo+1] as bits (+inf past the end)       lo = #{cdf <= g/G}
+    //   .z = idx[lo] | idx[lo+1] << 8 | idx[lo+2] << 16 | exceptional << 24      idx = pixel index (clamped to n-1)
+    //   .w = lo | hi << 16                                                        hi = #{cdf < (g+1)/G}
+    // so upper_bound(u) = lo + (cdf[lo] <= u) + (cdf[lo+1] <= u) and the pixel index comes out of the same 16 bytes.
+    // exceptional (hi - lo > 2): the sampler finishes with std::upper_bound over [lo, hi) of the reference arrays.
+    // The y-row record table (rowCells) is copied to LDS once per workgroup: a lens sample is ONE ds_read_b128 plus ONE
+    // global_load_dwordx4 (colCells[row*colCellCount + g]) instead of 15 dependent LDS reads + 5 global loads.
+    const uint32_t *rowCells;   // rowCellCount records of 4 dwords
+    const uint32_t *colCells;   // y * colCellCount records of 4 dwords
+    int32_t ldsWords;           // 4 * rowCellCount; 0: not available
+    int32_t rowCellCount;
+    int32_t colCellCount;
+    int32_t pad0;
 };
 
 }  // namespace zoic
