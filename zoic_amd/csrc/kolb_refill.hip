@@ -50,6 +50,22 @@ __device__ unsigned long long g_regionCycles[8];
 #define ZOIC_RT_FLUSH
 #endif
 
+// LDS -> HBM for the records a wave parked in its last pass.  `stage` holds the 64 record slots as 128 consecutive
+// 16-byte pieces, `stageIdx` the ray index per slot (0xffffffff: empty).  Lane j writes piece j, then piece 64 + j:
+// neighbouring lanes write the two halves of one record, and rays refilled together (consecutive indices in lane order)
+// mostly finish together, so one store instruction covers whole 32-byte sectors in long contiguous runs instead of 64
+// half-sectors at a 32-byte stride.
+__device__ __forceinline__ void flush_parked_records(RayRecord *out, const float4 *stage, const uint32_t *stageIdx, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        const uint32_t j = lane + 64u * h;
+        const uint32_t id = stageIdx[j >> 1];
+        const float4 piece = stage[j];
+        if (id != 0xffffffffu) reinterpret_cast<float4 *>(out + id)[j & 1u] = piece;
+    }
+}
+
 template <bool STRICT, int NS>
 __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_kernel(const KolbTable T, const BokehTables B,
                                                                    const float4 *__restrict__ samples,
@@ -71,6 +87,14 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
     }
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
+    // Deferred record stores.  vmcnt is ONE in-order counter for loads and stores: a store issued at the end of a pass
+    // would be waited for (write-acknowledge latency) by the first vmcnt(0) of the next pass -- the refill's window wait
+    // or the lens sampler's dependent cell load.  A finished ray is therefore parked in LDS (the wave's 64 record slots
+    // of 32 bytes + their ray indices) and written to HBM just before the NEXT trace, under which the stores and the
+    // window prefetch fly; every vmcnt wait then only meets operations that had a whole trace to complete.
+    float4 *stage = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords) + (threadIdx.x >> 6) * 144u;  // 128 pieces + 64 indices
+    uint32_t *stageIdx = reinterpret_cast<uint32_t *>(stage + 128);
+    bool parked = false;   // wave-uniform: records of the last pass wait in LDS
     // wave-uniform work window [next, end): a chunk of kChunkRays consecutive samples claimed from the global cursor
     uint32_t next = 0, end = 0;
     bool exhausted = false;
@@ -141,11 +165,6 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
                 active = true; fresh = true;
             }
             next += (nfree < avail) ? nfree : avail;
-            if (next < end) {       // re-base the window on the new cursor; consumed by the NEXT pass
-                const uint32_t wi = next + lane;
-                win = samples[wi < n ? wi : n - 1];
-                winBase = next;
-            }
             if (nfree <= avail) break;
             freeMask = __ballot(!active);
         }
@@ -210,6 +229,16 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         }
 
         ZOIC_RT_MARK(1)
+        // ---- re-base the sample window on the new cursor; consumed by the NEXT pass's refill ---------------------------
+        // Issued here, not in the refill: vmcnt is one in-order counter, so the lens sampler's dependent global load
+        // (cell record) waits for every older memory operation -- a window load issued before the search would be waited
+        // for, at full HBM latency, inside the search instead of flying under the trace.
+        if (next < end && winBase != next) {
+            const uint32_t wi = next + lane;
+            win = samples[wi < n ? wi : n - 1];
+            winBase = next;
+        }
+        if (parked) { flush_parked_records(out, stage, stageIdx, lane); parked = false; }
         // ---- one full trace for every lane that holds a candidate -----------------------------------------------------
         bool ok = false;
         const V3 oStart = o, dStart = d;
@@ -234,7 +263,11 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
             if constexpr (NS > 0) {
                 // the predicated trace does not keep the partial state of a failed ray; a ray that FINISHES failed
                 // (out of tries) gets it from the branchy trace, which stops at the failing interface
+#ifdef ZOIC_EXP_NO_PARTIAL
+                if (false) {
+#else
                 if (cand && !ok && tries > static_cast<uint32_t>(kMaxTries)) {
+#endif
                     uint32_t ignored = 0;
                     o = oStart; d = dStart;
                     if constexpr (STRICT) (void)trace_lens_strict(T, o, d, ignored);
@@ -247,16 +280,22 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         // (the predicated trace scribbles over the registers of lanes that ride along)
         ZOIC_RT_MARK(2)
         if (!cand) { o = oStart; d = dStart; }
+        uint32_t finishedIdx = 0xffffffffu;
         if (active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries))) {
             float w = 1.0f;
             if (tries > static_cast<uint32_t>(kMaxTries)) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
             if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
-            store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,  // zoic.cpp:1960-1961
-                             (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6));
+            stage[2 * lane] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);                 // zoic.cpp:1960-1961
+            stage[2 * lane + 1] = make_float4(d.y * -1.0f, d.z * -1.0f, w,
+                                              __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6)));
+            finishedIdx = idx;
             active = false;
         }
+        stageIdx[lane] = finishedIdx;
+        parked = true;
     }
 
+    if (parked) flush_parked_records(out, stage, stageIdx, lane);   // records parked by the last pass
     ZOIC_RT_FLUSH
     // ---- counters: wave reduction, one atomic per counter per wave ---------------------------------------------
     if (counters) {
@@ -302,7 +341,7 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
         // ZOIC_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the workgroups a CU admits
         static const size_t ldsPad = [] { const char *e = std::getenv("ZOIC_LDS_PAD"); return e ? static_cast<size_t>(std::atol(e)) : size_t(0); }();
-        const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + ldsPad;
+        const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + kWavesPerBlock * 144 * sizeof(float4) + ldsPad;
 #define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
     hipLaunchKernelGGL((kolb_refill_kernel<STRICT_, NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
                        rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords, chunkRays, minSearching)
