@@ -200,7 +200,7 @@ def main():
                        "gather": bool(args.gather and world > 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": ("kolb_refill_kernel<%s>" % ("false" if args.precision == "fast" else "true")) if cfg["params"]["lensModel"] == 1 else "thin_rays_kernel",
+                         "kernel": ("kolb_refill_%s_kernel" % args.precision) if cfg["params"]["lensModel"] == 1 else "thin_rays_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_ray": ALGO_BYTES_PER_RAY,
                          "note": "Kolb path is FP32-VALU bound (DESIGN.md); HBM fraction reported per the bench contract"},
             "zero_weight_frac": round(counters["vignettedRays"] / max(done, 1), 5),

@@ -4,6 +4,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/op_rate.hip -o /tmp/op_rate ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -54,7 +56,13 @@
     X(43, "v_div_scale_f32", "v_div_scale_f32 %0, vcc, %0, %2, %3") \
     X(44, "v_ldexp_f32", "v_ldexp_f32 %0, %0, %2") \
     X(45, "v_frexp_mant_f32", "v_frexp_mant_f32 %0, %0") \
-    X(46, "ds_bpermute_b32", "ds_bpermute_b32 %0, %2, %0\n s_waitcnt lgkmcnt(0)")
+    X(46, "ds_bpermute_b32", "ds_bpermute_b32 %0, %2, %0\n s_waitcnt lgkmcnt(0)") \
+    X(47, "MIX fma,cvt (x2)", "v_fma_f32 %0, %0, %2, %3\n v_cvt_f32_u32 %0, %0") \
+    X(48, "MIX fma,fma,fma,cvt (x4)", "v_fma_f32 %0, %0, %2, %3\n v_mul_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_cvt_f32_u32 %0, %0") \
+    X(49, "MIX fma,cmp->s (x2)", "v_fma_f32 %0, %0, %2, %3\n v_cmp_gt_f32 s[20:21], %0, %2") \
+    X(50, "MIX mul,add (x2)", "v_mul_f32 %0, %0, %2\n v_add_f32 %0, %0, %3") \
+    X(51, "MIX fma,sqrt (x2)", "v_fma_f32 %0, %0, %2, %3\n v_sqrt_f32 %0, %0") \
+    X(52, "MIX 6 fp32,sqrt (x7)", "v_fma_f32 %0, %0, %2, %3\n v_mul_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_fma_f32 %0, %0, %2, %3\n v_mul_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_sqrt_f32 %0, %0")
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, int iters, float a0)
@@ -86,6 +94,8 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
 template <int OP>
 void run(const char *name, float *d, unsigned long long *dc)
 {
+    int perOp = 1;   // instructions per asm statement: "(xN)" in the name
+    if (const char *x = strstr(name, "(x")) perOp = atoi(x + 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 1000;
     printf("%-30s", name);
@@ -98,7 +108,7 @@ void run(const char *name, float *d, unsigned long long *dc)
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long cyc = 0; hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost);
-        const double instrPerWave = double(iters) * 16 * 4;
+        const double instrPerWave = double(iters) * 16 * 4 * perOp;
         // s_memtime cycles per instruction per SIMD (the SIMD runs wavesPerSimd waves, each instrPerWave)
         const double cycPerInstr = double(cyc) / (instrPerWave * wavesPerSimd);
         const double wallRate = double(blocks) * 4 * instrPerWave / (ms * 1e-3) / 1e12;

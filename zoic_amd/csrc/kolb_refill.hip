@@ -31,10 +31,16 @@
 
 namespace zoic {
 
-// SGPR budget: a 256-lane workgroup is admitted per CU up to floor(800 / (ceil(sgpr/16)*16 + 16)) times
-// (MI355X_MICROARCH.md): 106 SGPRs -> 6 workgroups, <= 96 -> 7.  Capping at 94 measured +4.5 % on C3.
-#ifndef ZOIC_REFILL_ATTR
-#define ZOIC_REFILL_ATTR __attribute__((amdgpu_num_sgpr(94)))
+// Register budgets.  SGPRs: a 256-lane workgroup is admitted per CU up to floor(800 / (ceil(sgpr/16)*16 + 16)) times
+// (MI355X_MICROARCH.md): 106 SGPRs -> 6 workgroups, <= 96 -> 7; capping at 94 measured +4.5 % on C3.  VGPRs: the fast
+// instantiations need 73 (72 + the SGPR-spill register), one over the 7-waves-per-SIMD line (512 / 7 -> 72); asking
+// for 7 waves costs a few spilled dwords and measured +4 % on C3.  The strict instantiations (127-137 VGPRs, f64
+// intermediates) stay at the compiler's choice.
+#ifndef ZOIC_REFILL_ATTR_STRICT
+#define ZOIC_REFILL_ATTR_STRICT __attribute__((amdgpu_num_sgpr(94)))
+#endif
+#ifndef ZOIC_REFILL_ATTR_FAST
+#define ZOIC_REFILL_ATTR_FAST __attribute__((amdgpu_num_sgpr(94), amdgpu_waves_per_eu(7, 8)))
 #endif
 
 // Debug build only (-DZOIC_REGION_TIMERS, tools/region_times.py): per-wave s_memtime cycles spent in each region of the
@@ -67,11 +73,10 @@ __device__ __forceinline__ void flush_parked_records(RayRecord *out, const float
 }
 
 template <bool STRICT, int NS>
-__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_kernel(const KolbTable T, const BokehTables B,
-                                                                   const float4 *__restrict__ samples,
-                                                                   const uint4 *__restrict__ rngStates, uint64_t rayBase,
-                                                                   uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters,
-                                                                   unsigned int *__restrict__ workCursor, uint32_t ldsWords, uint32_t chunkRays, uint32_t minSearching)
+__device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
+                                                 const uint4 *__restrict__ rngStates, uint64_t rayBase, uint32_t n,
+                                                 RayRecord *__restrict__ out, DeviceCounters *counters,
+                                                 unsigned int *__restrict__ workCursor, uint32_t ldsWords, uint32_t chunkRays, uint32_t minSearching)
 {
     const uint32_t lane = threadIdx.x & 63u;
     // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
     uint32_t idx = 0, tries = 0, lutMiss = 0;
     float o0x = 0, o0y = 0, maxScale = 0, translation = 0, sn = 0, cs = 1, u = 0, v = 0;
     Rng rng{1, 2, 3, 4};
-    uint32_t succ = 0, vign = 0, tir = 0;
+    uint32_t succ = 0, vign = 0, tir = 0;   // wave totals, wave-uniform (SGPRs: ballot + popcount, no per-lane counters)
     ZOIC_RT_DECL
 
     for (;;) {
@@ -244,22 +249,22 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         const V3 oStart = o, dStart = d;
         const bool firstTry = tries == 0;
         if (__ballot(cand) != 0ull) {
-            const uint32_t tirBefore = tir;
+            uint32_t tirTry = 0;   // 0/1: this try ended in total internal reflection
             if constexpr (NS > 0) {
-                if constexpr (STRICT) ok = trace_lens_strict_pred<NS>(T, o, d, tir, cand);
-                else ok = trace_lens_fast_pred<NS>(T.fsurf, o, d, tir, cand);
+                if constexpr (STRICT) ok = trace_lens_strict_pred<NS>(T, o, d, tirTry, cand);
+                else ok = trace_lens_fast_pred<NS>(T.fsurf, o, d, tirTry, cand);
 #ifdef ZOIC_EXP_DOUBLE_TRACE
                 if constexpr (!STRICT) { V3 o2 = oStart, d2 = dStart; uint32_t t2 = 0; o2.x += o.x * 0.0f; const bool ok2 = trace_lens_fast_pred<NS>(T.fsurf, o2, d2, t2, cand); o.x += o2.x * 0.0f; ok = ok & (ok2 | !ok); }
 #endif
             } else if (cand) {
-                if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tir);
-                else ok = trace_lens_fast_rolled(T, o, d, tir);
+                if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
+                else ok = trace_lens_fast_rolled(T, o, d, tirTry);
             }
-            if (cand && !ok && firstTry && dead && finiteSample) {
-                // 26 more identical failures: account for their TIR bumps, then finish the ray as the reference would
-                tir += (tir - tirBefore) * (static_cast<uint32_t>(kMaxTries) + 1u);
-                tries = static_cast<uint32_t>(kMaxTries) + 1u;
-            }
+            const bool shortcut = cand && !ok && firstTry && dead && finiteSample;
+            // the shortcut stands for 26 more identical failures: account for their TIR bumps as well
+            tir += static_cast<uint32_t>(__popcll(__ballot(tirTry != 0u))) +
+                   (static_cast<uint32_t>(kMaxTries) + 1u) * static_cast<uint32_t>(__popcll(__ballot(shortcut && tirTry != 0u)));
+            if (shortcut) tries = static_cast<uint32_t>(kMaxTries) + 1u;   // ... then finish the ray as the reference would
             if constexpr (NS > 0) {
                 // the predicated trace does not keep the partial state of a failed ray; a ray that FINISHES failed
                 // (out of tries) gets it from the branchy trace, which stops at the failing interface
@@ -281,9 +286,14 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         ZOIC_RT_MARK(2)
         if (!cand) { o = oStart; d = dStart; }
         uint32_t finishedIdx = 0xffffffffu;
-        if (active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries))) {
-            float w = 1.0f;
-            if (tries > static_cast<uint32_t>(kMaxTries)) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
+        const bool finished = active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries));
+        {
+            const uint32_t nv = static_cast<uint32_t>(__popcll(__ballot(finished && tries > static_cast<uint32_t>(kMaxTries))));
+            vign += nv;                                                                       // zoic.cpp:1951-1957
+            succ += static_cast<uint32_t>(__popcll(__ballot(finished))) - nv;
+        }
+        if (finished) {
+            float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;
             if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
             stage[2 * lane] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);                 // zoic.cpp:1960-1961
             stage[2 * lane + 1] = make_float4(d.y * -1.0f, d.z * -1.0f, w,
@@ -297,13 +307,8 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
 
     if (parked) flush_parked_records(out, stage, stageIdx, lane);   // records parked by the last pass
     ZOIC_RT_FLUSH
-    // ---- counters: wave reduction, one atomic per counter per wave ---------------------------------------------
+    // ---- counters: the wave totals, one atomic per counter per wave ---------------------------------------------
     if (counters) {
-        for (int off = 32; off > 0; off >>= 1) {
-            succ += __shfl_down(succ, off, 64);
-            vign += __shfl_down(vign, off, 64);
-            tir += __shfl_down(tir, off, 64);
-        }
         if (lane == 0) {
             if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
             if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
@@ -311,6 +316,22 @@ __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR void kolb_refill_ker
         }
     }
 }
+
+// the two precisions are separate kernels only so that each can carry its own register-budget attributes
+#define ZOIC_REFILL_PARAMS const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, \
+        uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,          \
+        uint32_t ldsWords, uint32_t chunkRays, uint32_t minSearching
+template <int NS>
+__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_STRICT void kolb_refill_strict_kernel(ZOIC_REFILL_PARAMS)
+{
+    kolb_refill_body<true, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, minSearching);
+}
+template <int NS>
+__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_FAST void kolb_refill_fast_kernel(ZOIC_REFILL_PARAMS)
+{
+    kolb_refill_body<false, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, minSearching);
+}
+#undef ZOIC_REFILL_PARAMS
 
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                        uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
@@ -342,8 +363,10 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         // ZOIC_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the workgroups a CU admits
         static const size_t ldsPad = [] { const char *e = std::getenv("ZOIC_LDS_PAD"); return e ? static_cast<size_t>(std::atol(e)) : size_t(0); }();
         const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + kWavesPerBlock * 144 * sizeof(float4) + ldsPad;
+#define ZOIC_REFILL_KERNEL_true kolb_refill_strict_kernel
+#define ZOIC_REFILL_KERNEL_false kolb_refill_fast_kernel
 #define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
-    hipLaunchKernelGGL((kolb_refill_kernel<STRICT_, NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
+    hipLaunchKernelGGL((ZOIC_REFILL_KERNEL_##STRICT_<NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
                        rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords, chunkRays, minSearching)
         if (!fast) switch (table.lensCount) {
             case 7: ZOIC_LAUNCH_REFILL(true, 7); break;
@@ -364,6 +387,8 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
             default: ZOIC_LAUNCH_REFILL(false, 0); break;
         }
 #undef ZOIC_LAUNCH_REFILL
+#undef ZOIC_REFILL_KERNEL_true
+#undef ZOIC_REFILL_KERNEL_false
         e = hipGetLastError();
         if (e != hipSuccess) return static_cast<int>(e);
     }
