@@ -35,9 +35,9 @@ namespace zoic {
 // (MI355X_MICROARCH.md): 106 SGPRs -> 6 workgroups, <= 96 -> 7; capping at 94 measured +4.5 % on C3.  VGPRs: the fast
 // instantiations need 73 (72 + the SGPR-spill register), one over the 7-waves-per-SIMD line (512 / 7 -> 72); asking
 // for 7 waves costs a few spilled dwords and measured +4 % on C3.  The strict instantiations (127-137 VGPRs, f64
-// intermediates) stay at the compiler's choice.
+// intermediates) are held to 128 = 4 waves per SIMD (3 otherwise): +6-8 % (5 waves = 96 VGPRs spills too much: -12 %).
 #ifndef ZOIC_REFILL_ATTR_STRICT
-#define ZOIC_REFILL_ATTR_STRICT __attribute__((amdgpu_num_sgpr(94)))
+#define ZOIC_REFILL_ATTR_STRICT __attribute__((amdgpu_num_sgpr(94), amdgpu_waves_per_eu(4, 4)))
 #endif
 #ifndef ZOIC_REFILL_ATTR_FAST
 #define ZOIC_REFILL_ATTR_FAST __attribute__((amdgpu_num_sgpr(94), amdgpu_waves_per_eu(7, 8)))
