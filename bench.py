@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_RAY = 48  # 16 B sample in + one 32 B ray record out (28 B origin/dir/weight of SURVEY 8(d) + the 4 B flag word)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3
-VALU_PEAK_TWIPS = 0.95   # T wave64 VALU instr/s, whole chip, plain f32 ops at >= 4 waves/SIMD (tools/ubench/valu_rate.hip on MI355X)
+VALU_PEAK_TWIPS = 0.95   # T wave64 VALU instr/s, whole chip: plain f32 ops / mixed streams at >= 4 waves/SIMD (tools/ubench/op_rate.hip on MI355X, profiles/ubench_r01.txt)
 
 
 def parse_args():
@@ -186,7 +186,7 @@ def main():
                     valu = {"bound": "valu-issue", "achieved": round(rate, 4), "peak": VALU_PEAK_TWIPS, "unit": "T wave64-instr/s",
                             "frac": round(rate / VALU_PEAK_TWIPS, 4), "lane_instr_per_ray": round(ent["lane_instr_per_ray"], 1),
                             "lane_utilisation": round(ent.get("valu_thread_util", 0.0), 3),
-                            "note": "peak = measured plain-VALU issue rate (tools/ubench/valu_rate.hip); instruction count from profiles/ PMC"}
+                            "note": "peak = measured VALU issue rate of plain-f32 / mixed streams (tools/ubench/op_rate.hip); instruction count from profiles/ PMC"}
             except Exception:
                 traffic, valu = None, None
         line = {
