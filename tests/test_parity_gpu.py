@@ -313,7 +313,8 @@ def test_generic_interface_count_path(gpu, oracle_lib, text):
     assert 1.0 - float(same.mean()) < FLIP_TOL
 
 
-@pytest.mark.parametrize("shape,kind", [((256, 256), "falloff"), ((150, 200), "falloff"), ((64, 48), "spots"), ((256, 256), "spots")])
+@pytest.mark.parametrize("shape,kind", [((256, 256), "falloff"), ((150, 200), "falloff"), ((64, 48), "spots"), ((256, 256), "spots"),
+                                        ((512, 512), "hexagon"), ((700, 1000), "falloff"), ((1100, 300), "spots")])
 def test_bokeh_cell_records_exact_on_dense_cells(gpu, oracle_lib, shape, kind):
     """The cell-record sampler (one LDS record + one global record per lens sample) must return std::upper_bound's pixel
     for every sample: images whose sorted CDFs crowd many entries into one cell (exponential falloff; a few bright spots on
@@ -322,7 +323,9 @@ def test_bokeh_cell_records_exact_on_dense_cells(gpu, oracle_lib, shape, kind):
     h, w = shape
     rs = np.random.RandomState(11)
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    if kind == "falloff":
+    if kind == "hexagon":
+        lum = hexagon_bokeh(h)[:, :, 0].astype(np.float32)
+    elif kind == "falloff":
         lum = np.exp(-((xx - w / 2) ** 2 + (yy - h / 2) ** 2) / (0.02 * w * h)).astype(np.float32) + 1e-6 * rs.rand(h, w).astype(np.float32)
     else:
         lum = 1e-4 * rs.rand(h, w).astype(np.float32)

@@ -235,8 +235,9 @@ zoic_status upload_bokeh(zoic_camera *cam)
         B.colCount[j] = cshape.count[j];
     }
     B.levels = levels;
-    // cell records (tables.hpp) for images up to 256 x 256 with non-decreasing CDFs
-    if (im.x <= 256 && im.y <= 256) {
+    // cell records (tables.hpp): rows <= 2048 (the row records live in LDS: 32 KB at most), columns <= 4096, both CDFs
+    // non-decreasing and NaN-free (anything else keeps the pyramid / reference search)
+    if (im.x <= 4096 && im.y <= 2048) {
         const auto monotone = [](const float *a, int n) {
             for (int i = 0; i < n; ++i) if (!(a[i] == a[i]) || (i > 0 && a[i] < a[i - 1])) return false;
             return true;
@@ -246,33 +247,38 @@ zoic_status upload_bokeh(zoic_camera *cam)
         if (ok) {
             const auto cellCount = [](int n) { int g = 16; while (g < n) g <<= 1; return g; };
             const int gRow = cellCount(im.y), gCol = cellCount(im.x);
-            std::vector<uint32_t> cells((static_cast<size_t>(gRow) + y * static_cast<size_t>(gCol)) * 4);
-            // records of one CDF: cdf[n] non-decreasing, idx[n] pixel indices relative to `idxBase` (each < 256)
-            const auto fill = [](const float *cdf, const int32_t *idx, int32_t idxBase, int n, int g, uint32_t *out) {
-                for (int c = 0; c < g; ++c) {
+            const size_t nCells = static_cast<size_t>(gRow) + y * static_cast<size_t>(gCol);
+            std::vector<uint32_t> cells(nCells * 5);          // records (4 dwords each), then the bounds (1 dword each)
+            uint32_t *bounds = cells.data() + nCells * 4;
+            // records of one CDF: cdf[n] non-decreasing, idx[n] pixel indices relative to `idxBase` (each < 65536)
+            const auto fill = [](const float *cdf, const int32_t *idx, int32_t idxBase, int n, int g, uint32_t *rec, uint32_t *bnd) {
+                int lo = 0, hi = 0;                            // both only move forward as the cell edge grows
+                for (int c = 0; c < g; ++c, rec += 4, ++bnd) {
                     const float lower = static_cast<float>(c) / static_cast<float>(g), upper = static_cast<float>(c + 1) / static_cast<float>(g);
-                    const int lo = static_cast<int>(std::upper_bound(cdf, cdf + n, lower) - cdf);   // #{cdf <= lower}
-                    const int hi = static_cast<int>(std::lower_bound(cdf, cdf + n, upper) - cdf);   // #{cdf <  upper}
+                    while (lo < n && cdf[lo] <= lower) ++lo;   // lo = #{cdf <= lower}
+                    if (hi < lo) hi = lo;
+                    while (hi < n && cdf[hi] < upper) ++hi;    // hi = #{cdf <  upper}
                     const float inf = INFINITY;
                     const float a = lo < n ? cdf[lo] : inf, b = lo + 1 < n ? cdf[lo + 1] : inf;
-                    uint32_t packed = (hi - lo > 2) ? (1u << 24) : 0u;
-                    for (int k = 0; k < 3; ++k)
-                        packed |= static_cast<uint32_t>((idx[std::min(lo + k, n - 1)] - idxBase) & 0xff) << (8 * k);
-                    uint32_t *rec = out + static_cast<size_t>(c) * 4;
+                    uint32_t id[3];
+                    for (int k = 0; k < 3; ++k) id[k] = static_cast<uint32_t>(idx[std::min(lo + k, n - 1)] - idxBase) & 0xffffu;
                     std::memcpy(rec + 0, &a, 4);
                     std::memcpy(rec + 1, &b, 4);
-                    rec[2] = packed;
-                    rec[3] = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
+                    rec[2] = id[0] | (id[1] << 16);
+                    rec[3] = id[2] | ((hi - lo > 2) ? 0x80000000u : 0u);
+                    *bnd = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
                 }
             };
-            fill(im.cdfRow.data(), im.rowIndices.data(), 0, im.y, gRow, cells.data());
+            fill(im.cdfRow.data(), im.rowIndices.data(), 0, im.y, gRow, cells.data(), bounds);
             for (size_t r = 0; r < y; ++r)
                 fill(im.cdfColumn.data() + r * im.x, im.columnIndices.data() + r * im.x, static_cast<int32_t>(r * im.x), im.x, gCol,
-                     cells.data() + (static_cast<size_t>(gRow) + r * gCol) * 4);
+                     cells.data() + (static_cast<size_t>(gRow) + r * gCol) * 4, bounds + gRow + r * gCol);
             ZOIC_HIP(cam->dBokehCells.reserve(cells.size()));
             ZOIC_HIP(hipMemcpy(cam->dBokehCells.ptr, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             B.rowCells = cam->dBokehCells.ptr;
             B.colCells = cam->dBokehCells.ptr + static_cast<size_t>(gRow) * 4;
+            B.rowBounds = cam->dBokehCells.ptr + nCells * 4;
+            B.colBounds = B.rowBounds + gRow;
             B.ldsWords = gRow * 4;
             B.rowCellCount = gRow;
             B.colCellCount = gCol;

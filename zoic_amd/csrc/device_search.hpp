@@ -58,30 +58,21 @@ __device__ __forceinline__ V2 bokeh_sample_device(const BokehTables &B, int x, i
     return V2{(flippedRow / static_cast<float>(x)) * 2.0f, (flippedColumn / static_cast<float>(y)) * 2.0f};
 }
 
-// One CDF resolved through its cell record (tables.hpp).  Returns the pixel index; identical to
-// indices[min(upper_bound(cdf, u), n-1)] for every u (NaN, negative and >= 1 samples take the exceptional path).
-struct CellLookup {
-    int index;      // pixel index when !exceptional
-    bool exceptional;
-    int lo, hi;     // upper_bound lies in [lo, hi] (exceptional path)
-};
-
+// One CDF resolved through its cell record (tables.hpp): the pixel index, identical to
+// indices[min(upper_bound(cdf, u), n-1)] unless the cell is exceptional (then the caller finishes with upper_bound).
 __device__ __forceinline__ int cell_of(float u, int cellCount, bool &inRange)
 {
     inRange = (u >= 0.0f) & (u < 1.0f);
     return inRange ? static_cast<int>(u * static_cast<float>(cellCount)) : 0;   // exact: cellCount is a power of two
 }
 
-__device__ __forceinline__ CellLookup cell_resolve(const uint4 rec, float u, bool inRange, int n)
+__device__ __forceinline__ int cell_resolve(const uint4 rec, float u, bool inRange, bool &exceptional)
 {
     const float a = __builtin_bit_cast(float, rec.x), b = __builtin_bit_cast(float, rec.y);
-    const int k = (!(u < a) ? 1 : 0) + (!(u < b) ? 1 : 0);
-    CellLookup r;
-    r.index = static_cast<int>((rec.z >> (8 * k)) & 0xffu);
-    r.exceptional = ((rec.z >> 24) != 0u) | !inRange;
-    r.lo = inRange ? static_cast<int>(rec.w & 0xffffu) : 0;
-    r.hi = inRange ? static_cast<int>(rec.w >> 16) : n;
-    return r;
+    const bool ge0 = !(u < a), ge1 = !(u < b);          // sorted: ge1 implies ge0
+    exceptional = ((rec.w >> 31) != 0u) | !inRange;
+    const uint32_t pair = ge1 ? rec.w : rec.z;           // k = 2 -> idx[lo+2] (low half of .w)
+    return static_cast<int>((ge0 & !ge1) ? (pair >> 16) : (pair & 0xffffu));   // k = 1 -> high half of .z
 }
 
 // Lens sample through the cell records: `ldsRowCells` = the workgroup's LDS copy of BokehTables::rowCells.
@@ -89,25 +80,27 @@ __device__ __forceinline__ CellLookup cell_resolve(const uint4 rec, float u, boo
 template <bool EXACT_DIVIDE>
 __device__ __forceinline__ V2 bokeh_sample_cells(const BokehTables &B, const float *ldsRowCells, int x, int y, float uRow, float uCol)
 {
-    bool inR, inC;
+    bool inR, inC, excR, excC;
     const int gr = cell_of(uRow, B.rowCellCount, inR);
     const int gc = cell_of(uCol, B.colCellCount, inC);
-    const CellLookup R = cell_resolve(reinterpret_cast<const uint4 *>(ldsRowCells)[gr], uRow, inR, y);
-    int row = R.index;
-    if (__ballot(R.exceptional) != 0ull) {          // rare, wave-uniform: dense cell or a sample outside [0,1)
-        if (R.exceptional) {
-            int r = R.lo + upper_bound_idx(B.cdfRow + R.lo, R.hi - R.lo, uRow);
+    int row = cell_resolve(reinterpret_cast<const uint4 *>(ldsRowCells)[gr], uRow, inR, excR);
+    if (__ballot(excR) != 0ull) {          // rare, wave-uniform: dense cell or a sample outside [0,1)
+        if (excR) {
+            const uint32_t bnd = B.rowBounds[gr];
+            const int lo = inR ? static_cast<int>(bnd & 0xffffu) : 0, hi = inR ? static_cast<int>(bnd >> 16) : y;
+            int r = lo + upper_bound_idx(B.cdfRow + lo, hi - lo, uRow);
             if (r >= y) r = y - 1;
             row = B.rowIndices[r];
         }
     }
-    const uint4 crec = reinterpret_cast<const uint4 *>(B.colCells)[static_cast<uint32_t>(row) * static_cast<uint32_t>(B.colCellCount) + static_cast<uint32_t>(gc)];
-    const CellLookup Cc = cell_resolve(crec, uCol, inC, x);
-    int col = Cc.index;
-    if (__ballot(Cc.exceptional) != 0ull) {
-        if (Cc.exceptional) {
+    const uint32_t cellIndex = static_cast<uint32_t>(row) * static_cast<uint32_t>(B.colCellCount) + static_cast<uint32_t>(gc);
+    int col = cell_resolve(reinterpret_cast<const uint4 *>(B.colCells)[cellIndex], uCol, inC, excC);
+    if (__ballot(excC) != 0ull) {
+        if (excC) {
+            const uint32_t bnd = B.colBounds[cellIndex];
+            const int lo = inC ? static_cast<int>(bnd & 0xffffu) : 0, hi = inC ? static_cast<int>(bnd >> 16) : x;
             const int start = row * x;
-            int c = Cc.lo + upper_bound_idx(B.cdfColumn + start + Cc.lo, Cc.hi - Cc.lo, uCol);
+            int c = lo + upper_bound_idx(B.cdfColumn + start + lo, hi - lo, uCol);
             if (c >= x) c = x - 1;
             col = B.columnIndices[start + c] - start;
         }

@@ -101,19 +101,22 @@ struct BokehTables {
     int32_t rowCount[kBokehMaxLevels];       // valid entries per level of the row pyramid
     int32_t colCount[kBokehMaxLevels];       // valid entries per level of one column pyramid row
     int32_t levels;                          // 0: pyramid not built (CDF longer than 4096) -> binary search
-    // Cell records (x, y <= 256; built when both CDFs are non-decreasing): the unit interval of the sample is cut into
-    // G = 2^k >= n cells; for cell g = floor(u*G) (exact: G is a power of two) the record holds everything
+    // Cell records (y <= 2048, x <= 4096; built when both CDFs are non-decreasing): the unit interval of the sample is
+    // cut into G = 2^k >= n cells; for cell g = floor(u*G) (exact: G is a power of two) the record holds everything
     // std::upper_bound needs when at most two CDF entries fall inside the cell:
     //   .x = cdf[lo] as bits, .y = cdf[lo+1] as bits (+inf past the end)       lo = #{cdf <= g/G}
-    //   .z = idx[lo] | idx[lo+1] << 8 | idx[lo+2] << 16 | exceptional << 24      idx = pixel index (clamped to n-1)
-    //   .w = lo | hi << 16                                                        hi = #{cdf < (g+1)/G}
+    //   .z = idx[lo] | idx[lo+1] << 16                                           idx = pixel index (clamped to n-1)
+    //   .w = idx[lo+2] | exceptional << 31                                       exceptional: #{g/G < cdf < (g+1)/G} > 2
     // so upper_bound(u) = lo + (cdf[lo] <= u) + (cdf[lo+1] <= u) and the pixel index comes out of the same 16 bytes.
-    // exceptional (hi - lo > 2): the sampler finishes with std::upper_bound over [lo, hi) of the reference arrays.
-    // The y-row record table (rowCells) is copied to LDS once per workgroup: a lens sample is ONE ds_read_b128 plus ONE
+    // Exceptional cells finish with std::upper_bound over [lo, hi) of the reference arrays; their bounds
+    // (lo | hi << 16, hi = #{cdf < (g+1)/G}) sit in side tables only that path reads.
+    // The row record table (rowCells) is copied to LDS once per workgroup: a lens sample is ONE ds_read_b128 plus ONE
     // global_load_dwordx4 (colCells[row*colCellCount + g]) instead of 15 dependent LDS reads + 5 global loads.
-    const uint32_t *rowCells;   // rowCellCount records of 4 dwords
-    const uint32_t *colCells;   // y * colCellCount records of 4 dwords
-    int32_t ldsWords;           // 4 * rowCellCount; 0: not available
+    const uint32_t *rowCells;    // rowCellCount records of 4 dwords
+    const uint32_t *colCells;    // y * colCellCount records of 4 dwords
+    const uint32_t *rowBounds;   // rowCellCount
+    const uint32_t *colBounds;   // y * colCellCount
+    int32_t ldsWords;            // 4 * rowCellCount; 0: not available
     int32_t rowCellCount;
     int32_t colCellCount;
     int32_t pad0;
