@@ -51,11 +51,17 @@ __device__ __forceinline__ void flush_counters(DeviceCounters *c, uint32_t succ,
     }
 }
 
-__device__ __forceinline__ V2 sample_lens(bool useImage, const BokehTables &B, int bw, int bh, float u, float v)
+// rowCellsLds: the workgroup's LDS copy of the bokeh row cell records (nullptr: pyramid / reference search)
+__device__ __forceinline__ V2 sample_lens(bool useImage, const BokehTables &B, const float *rowCellsLds, int bw, int bh, float u, float v)
 {
-    if (useImage) return bokeh_sample_device(B, bw, bh, u, v);
+    if (useImage) {
+        if (rowCellsLds) return bokeh_sample_cells<true>(B, rowCellsLds, bw, bh, u, v);
+        return bokeh_sample_device(B, bw, bh, u, v);
+    }
     return concentric_disk(u, v);
 }
+
+extern __shared__ __align__(16) float thinDynLds[];   // bokeh row cell records (thin-lens kernel), after the static LDS
 
 // ------------------------------------------------------------------------------------- RAYTRACED, strict
 __global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTable T, const BokehTables B,
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTabl
 {
     uint32_t succ = 0, vign = 0, tir = 0;
     const bool useImage = T.useImage != 0;
+    const float *rowCells = nullptr;   // the A/B baseline kernel keeps the pyramid search
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
         const float4 s = samples[i];  // (sx, sy, lensx, lensy)
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTabl
 
         // sensor point, zoic.cpp:1853-1855
         const V3 o0{s.x * T.halfSensor, s.y * T.halfSensor, T.originShift};
-        V2 lens = sample_lens(useImage, B, T.bokehW, T.bokehH, s.z, s.w);  // zoic.cpp:1870
+        V2 lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, s.z, s.w);  // zoic.cpp:1870
         float maxScale = 0.0f, translation = 0.0f, sn = 0.0f, cs = 1.0f;
         uint32_t lutMiss = 0;
         V3 o = o0, d;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTabl
             o = o0;
             const float u = rng_unit(xor128(rng));
             const float v = rng_unit(xor128(rng));
-            lens = sample_lens(useImage, B, T.bokehW, T.bokehH, u, v);
+            lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, u, v);
             if (!T.useLUT) {
                 d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
             } else {
@@ -128,11 +135,17 @@ __device__ __forceinline__ bool optical_vignet_pass(const ThinTable &T, V3 origi
 __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, const BokehTables B,
                                                            const float4 *__restrict__ samples,
                                                            const uint4 *__restrict__ rngStates, uint64_t rayBase, uint64_t n,
-                                                           RayRecord *__restrict__ out, DeviceCounters *counters)
+                                                           RayRecord *__restrict__ out, DeviceCounters *counters, uint32_t ldsWords)
 {
     uint32_t succ = 0, vign = 0;
     const bool useImage = T.useImage != 0;
     __shared__ float4 stage[kBlock / 64][128];   // per-wave transpose buffer for the coalesced record store
+    const float *rowCells = nullptr;
+    if (ldsWords > 0) {                          // bokeh row cell records, once per workgroup (tables.hpp)
+        for (uint32_t i = threadIdx.x; i < ldsWords; i += kBlock) thinDynLds[i] = __builtin_bit_cast(float, B.rowCells[i]);
+        rowCells = thinDynLds;
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     // software pipeline: the sample of the wave's NEXT tile is requested before the current one is evaluated
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
         int tries = 0;
         float w = 1.0f;
         if (T.useDof) {
-            V2 lens = sample_lens(useImage, B, T.bokehW, T.bokehH, s.z, s.w);
+            V2 lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, s.z, s.w);
             lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
             origin = V3{lens.x, lens.y, 0.0f};
             const float inter = fabsf(T.focalDistance / dir0.z);
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
                     }
                     const float u = rng_unit(xor128(rng));
                     const float v = rng_unit(xor128(rng));
-                    lens = sample_lens(useImage, B, T.bokehW, T.bokehH, u, v);
+                    lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, u, v);
                     lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
                     origin = V3{lens.x, lens.y, 0.0f};
                     dir = normalize3(V3{fp.x - origin.x, fp.y - origin.y, fp.z - origin.z});  // dir0, inter, fp are loop invariant
@@ -282,9 +295,10 @@ int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const flo
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, void *stream)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(thin_rays_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,
-                       reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,
-                       d_counters);
+    const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
+    hipLaunchKernelGGL(thin_rays_kernel, dim3(grid_for(n)), dim3(kBlock), ldsWords * sizeof(float), static_cast<hipStream_t>(stream),
+                       table, bokeh, reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,
+                       d_counters, ldsWords);
     return static_cast<int>(hipGetLastError());
 }
 
