@@ -349,11 +349,14 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         const uint64_t tiles = (m + 63) / 64;
         const uint64_t wantBlocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned grid = static_cast<unsigned>(wantBlocks < 2048 ? (wantBlocks ? wantBlocks : 1) : 2048);
-        // chunk = what one atomic claims: 1024 samples on big frames, down to one 64-sample tile on small ones, so that the
-        // dynamic cursor still has >= 8 chunks per wave to balance with
-        uint64_t chunk = m / (static_cast<uint64_t>(grid) * kWavesPerBlock * 8);
-        chunk = (chunk / 64) * 64;
-        const uint32_t chunkRays = static_cast<uint32_t>(chunk < 64 ? 64 : (chunk > kChunkRays ? kChunkRays : chunk));
+        // chunk = what one atomic claims.  All claims hit ONE address and the L2 serves about one of them per 12 ns
+        // (measured: 518 K claims of 256 samples take 6.3 ms on a frame that otherwise takes 4.0; 130 K claims of 64 take
+        // 1.75 ms on an 8.3 M-sample batch that takes 0.63 ms with 256), so a launch gets a budget of ~32 K claims:
+        // 64-sample tiles on small batches, 256 at 8 M samples, 512 at 16 M, 1024 from 33 M samples up.
+        // ZOIC_CHUNK_RAYS overrides the rule (experiments).
+        const uint64_t chunk = (m / 32768 + 63) / 64 * 64;
+        static const uint32_t chunkOverride = [] { const char *e = std::getenv("ZOIC_CHUNK_RAYS"); return e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }();
+        const uint32_t chunkRays = chunkOverride ? chunkOverride : static_cast<uint32_t>(chunk < 64 ? 64 : (chunk > kChunkRays ? kChunkRays : chunk));
         RayRecord *o = out + done;
         static const uint32_t minSearching = [] { const char *e = std::getenv("ZOIC_MIN_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kMinSearching; }();
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
