@@ -28,7 +28,7 @@ namespace {
 thread_local std::string g_lastError;
 
 constexpr unsigned kWorkCursors = 64;   // launches of one camera that may be in flight at once
-constexpr unsigned kCursorStride = 32;  // 128 bytes apart: one cursor per cache line
+constexpr unsigned kCursorStride = kCursorParts * kCursorPartStride;  // one launch's set of partition cursors (kernels.hpp)
 // a >2^31-sample call splits into several launches, each taking the next slot of the ring (kernels.hip)
 
 zoic_status fail(zoic_status s, const std::string &msg)

@@ -23,7 +23,11 @@ struct DeviceCounters {  // zoic.cpp:533-534: succesRays, vignettedRays, totalIn
 };
 
 // camera_create_ray, RAYTRACED branch (zoic.cpp:1850-1964) over n samples.  fast=false: strict arithmetic.
-// d_workCursor: one device word the persistent kernel uses as its chunk cursor (zeroed on the stream per launch).
+// d_workCursor: kCursorParts device words, kCursorPartStride dwords apart, the persistent kernel uses as its chunk cursors
+// (zeroed on the stream per launch).  One cursor per eighth of the batch: same-address atomics are served one per ~12 ns
+// by the L2, different addresses in parallel; a wave starts on its workgroup's home partition and moves on when it is empty.
+constexpr unsigned kCursorParts = 8;
+constexpr unsigned kCursorPartStride = 64;   // 256 bytes apart
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                      bool fast, void *stream);

@@ -76,7 +76,7 @@ template <bool STRICT, int NS>
 __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
                                                  const uint4 *__restrict__ rngStates, uint64_t rayBase, uint32_t n,
                                                  RayRecord *__restrict__ out, DeviceCounters *counters,
-                                                 unsigned int *__restrict__ workCursor, uint32_t ldsWords, uint32_t chunkRays, uint32_t minSearching)
+                                                 unsigned int *__restrict__ workCursor, uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching)
 {
     const uint32_t lane = threadIdx.x & 63u;
     // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the
@@ -103,6 +103,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     // wave-uniform work window [next, end): a chunk of kChunkRays consecutive samples claimed from the global cursor
     uint32_t next = 0, end = 0;
     bool exhausted = false;
+    uint32_t part = blockIdx.x % kCursorParts, partsTried = 0;   // the partition cursor this wave claims from (kernels.hpp)
     // sample prefetch window: lane l holds samples[winBase + l], loaded one pass ahead of its use so the HBM latency
     // hides under the trace; refilled lanes fetch their sample from lane `rank` with ds_bpermute (winBase == next)
     float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -121,11 +122,18 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         // ---- refill the free lanes from the work window (ballot + prefix sum) ---------------------------------
         unsigned long long freeMask = __ballot(!active);
         while (freeMask != 0ull && !exhausted) {
-            if (next >= end) {  // claim the next chunk: one atomic per kChunkRays samples per wave
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(workCursor, 1u);
-                c = __builtin_amdgcn_readfirstlane(c);
-                const uint64_t begin = static_cast<uint64_t>(c) * chunkRays;
+            if (next >= end) {  // claim the next chunk: one atomic per chunkRays samples per wave, on the partition's cursor
+                uint64_t begin = n;
+                while (partsTried < kCursorParts) {
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(workCursor + part * kCursorPartStride, 1u);
+                    c = __builtin_amdgcn_readfirstlane(c);
+                    begin = (static_cast<uint64_t>(part) * chunksPerPart + c) * chunkRays;
+                    if (c < chunksPerPart && begin < n) break;
+                    begin = n;                                   // this partition is used up: on to the next one, for good
+                    part = (part + 1u) % kCursorParts;
+                    ++partsTried;
+                }
                 if (begin >= n) { exhausted = true; break; }
                 next = static_cast<uint32_t>(begin);
                 end = (begin + chunkRays < n) ? static_cast<uint32_t>(begin + chunkRays) : n;
@@ -320,16 +328,16 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
 // the two precisions are separate kernels only so that each can carry its own register-budget attributes
 #define ZOIC_REFILL_PARAMS const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, \
         uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,          \
-        uint32_t ldsWords, uint32_t chunkRays, uint32_t minSearching
+        uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching
 template <int NS>
 __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_STRICT void kolb_refill_strict_kernel(ZOIC_REFILL_PARAMS)
 {
-    kolb_refill_body<true, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, minSearching);
+    kolb_refill_body<true, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, chunksPerPart, minSearching);
 }
 template <int NS>
 __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_FAST void kolb_refill_fast_kernel(ZOIC_REFILL_PARAMS)
 {
-    kolb_refill_body<false, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, minSearching);
+    kolb_refill_body<false, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, chunksPerPart, minSearching);
 }
 #undef ZOIC_REFILL_PARAMS
 
@@ -342,21 +350,25 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;
     for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
         const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
-        hipError_t e = hipMemsetAsync(d_workCursor, 0, sizeof(unsigned int), st);  // same stream as the kernel: ordered
+        hipError_t e = hipMemsetAsync(d_workCursor, 0, kCursorParts * kCursorPartStride * sizeof(unsigned int), st);  // same stream as the kernel: ordered
         if (e != hipSuccess) return static_cast<int>(e);
         // persistent waves: enough workgroups to fill every wave slot of 256 CUs (8 x 256 lanes per CU); late or
         // surplus workgroups find the cursor exhausted and retire at once, so residency need not be known exactly
         const uint64_t tiles = (m + 63) / 64;
         const uint64_t wantBlocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const unsigned grid = static_cast<unsigned>(wantBlocks < 2048 ? (wantBlocks ? wantBlocks : 1) : 2048);
-        // chunk = what one atomic claims.  All claims hit ONE address and the L2 serves about one of them per 12 ns
-        // (measured: 518 K claims of 256 samples take 6.3 ms on a frame that otherwise takes 4.0; 130 K claims of 64 take
-        // 1.75 ms on an 8.3 M-sample batch that takes 0.63 ms with 256), so a launch gets a budget of ~32 K claims:
-        // 64-sample tiles on small batches, 256 at 8 M samples, 512 at 16 M, 1024 from 33 M samples up.
-        // ZOIC_CHUNK_RAYS overrides the rule (experiments).
-        const uint64_t chunk = (m / 32768 + 63) / 64 * 64;
+        // chunk = what one atomic claims.  Claims on ONE address are served by the L2 at about one per 12 ns (measured:
+        // 518 K claims of 256 samples took 6.3 ms on a frame that otherwise takes 4.0; 130 K claims of 64 took 1.75 ms on
+        // an 8.3 M-sample batch that takes 0.63 ms with 256), so the batch is cut into kCursorParts partitions with a
+        // cursor each and a launch gets a budget of ~32 K claims per cursor: 512-sample chunks on a 4K x 16spp frame.
+        // Below 256 samples a wave changes chunk (an exposed atomic + window fetch) every few passes: not worth it unless
+        // the batch is small.  ZOIC_CHUNK_RAYS overrides the rule (experiments).
+        uint64_t chunk = (m / (32768ull * kCursorParts) + 63) / 64 * 64;
+        if (chunk < 256 && m >= (4ull << 20)) chunk = 256;
         static const uint32_t chunkOverride = [] { const char *e = std::getenv("ZOIC_CHUNK_RAYS"); return e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }();
         const uint32_t chunkRays = chunkOverride ? chunkOverride : static_cast<uint32_t>(chunk < 64 ? 64 : (chunk > kChunkRays ? kChunkRays : chunk));
+        const uint64_t totalChunks = (m + chunkRays - 1) / chunkRays;
+        const uint32_t chunksPerPart = static_cast<uint32_t>((totalChunks + kCursorParts - 1) / kCursorParts);
         RayRecord *o = out + done;
         static const uint32_t minSearching = [] { const char *e = std::getenv("ZOIC_MIN_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kMinSearching; }();
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
@@ -370,7 +382,7 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
 #define ZOIC_REFILL_KERNEL_false kolb_refill_fast_kernel
 #define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
     hipLaunchKernelGGL((ZOIC_REFILL_KERNEL_##STRICT_<NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
-                       rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords, chunkRays, minSearching)
+                       rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords, chunkRays, chunksPerPart, minSearching)
         if (!fast) switch (table.lensCount) {
             case 7: ZOIC_LAUNCH_REFILL(true, 7); break;
             case 8: ZOIC_LAUNCH_REFILL(true, 8); break;
