@@ -315,11 +315,16 @@ def test_generic_interface_count_path(gpu, oracle_lib, text):
 
 @pytest.mark.parametrize("shape,kind", [((256, 256), "falloff"), ((150, 200), "falloff"), ((64, 48), "spots"), ((256, 256), "spots"),
                                         ((512, 512), "hexagon"), ((700, 1000), "falloff"), ((1100, 300), "spots")])
-def test_bokeh_cell_records_exact_on_dense_cells(gpu, oracle_lib, shape, kind):
+@pytest.mark.parametrize("cells_on_host", [False, True])
+def test_bokeh_cell_records_exact_on_dense_cells(gpu, oracle_lib, monkeypatch, shape, kind, cells_on_host):
     """The cell-record sampler (one LDS record + one global record per lens sample) must return std::upper_bound's pixel
     for every sample: images whose sorted CDFs crowd many entries into one cell (exponential falloff; a few bright spots on
     a dim noisy background) exercise the exceptional path, and lens samples of exactly 0, 1.0, > 1, < 0 and NaN the
     out-of-range path.  Strict mode, bit-exact against the oracle (zoic.cpp:420-485)."""
+    if cells_on_host:
+        if shape not in ((150, 200), (1100, 300)):
+            pytest.skip("host build of the records: two shapes are enough")
+        monkeypatch.setenv("ZOIC_CELLS_HOST", "1")      # the records are built by the host loop instead of the GPU kernel
     h, w = shape
     rs = np.random.RandomState(11)
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)

@@ -123,6 +123,41 @@ __global__ void cdf_sort_columns(const float *__restrict__ pdf, const float *__r
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// Cell records of tables.hpp for every CDF of the image: block 0 = the row CDF (y entries, gRow cells), block 1 + r = the
+// column CDF of image row r (x entries, gCol cells).  One lane per cell: two binary searches and three index reads.
+__global__ void build_cells_kernel(const float *__restrict__ cdfRow, const int32_t *__restrict__ rowIdx, const float *__restrict__ cdfCol,
+                                   const int32_t *__restrict__ colIdx, int x, int y, int gRow, int gCol, uint32_t *__restrict__ rowCells,
+                                   uint32_t *__restrict__ colCells, uint32_t *__restrict__ rowBounds, uint32_t *__restrict__ colBounds)
+{
+    const bool isRow = blockIdx.x == 0;
+    const int r = static_cast<int>(blockIdx.x) - 1;
+    const float *cdf = isRow ? cdfRow : cdfCol + static_cast<size_t>(r) * x;
+    const int32_t *idx = isRow ? rowIdx : colIdx + static_cast<size_t>(r) * x;
+    const int32_t idxBase = isRow ? 0 : r * x;
+    const int n = isRow ? y : x, g = isRow ? gRow : gCol;
+    uint32_t *rec = isRow ? rowCells : colCells + static_cast<size_t>(r) * gCol * 4;
+    uint32_t *bnd = isRow ? rowBounds : colBounds + static_cast<size_t>(r) * gCol;
+    for (int c = threadIdx.x; c < g; c += blockDim.x) {
+        const float lower = static_cast<float>(c) / static_cast<float>(g), upper = static_cast<float>(c + 1) / static_cast<float>(g);
+        const int lo = upper_bound_idx(cdf, n, lower);                 // #{cdf <= lower}
+        int hi = lo, len = n - lo;                                     // lower_bound(upper) over [lo, n): #{cdf < upper}
+        while (len > 0) {
+            const int half = len >> 1;
+            if (cdf[hi + half] < upper) { hi += half + 1; len -= half + 1; } else len = half;
+        }
+        const float inf = __builtin_inff();
+        const float a = lo < n ? cdf[lo] : inf, b = lo + 1 < n ? cdf[lo + 1] : inf;
+        uint32_t id[3];
+        for (int k = 0; k < 3; ++k) { const int e = lo + k < n ? lo + k : n - 1; id[k] = static_cast<uint32_t>(idx[e] - idxBase) & 0xffffu; }
+        uint4 out;
+        out.x = __builtin_bit_cast(uint32_t, a); out.y = __builtin_bit_cast(uint32_t, b);
+        out.z = id[0] | (id[1] << 16);
+        out.w = id[2] | ((hi - lo > 2) ? 0x80000000u : 0u);
+        reinterpret_cast<uint4 *>(rec)[c] = out;
+        bnd[c] = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
+    }
+}
+
 }  // namespace
 
 // Returns 0 on success (tables in `out`), >0 = hipError_t, -1 = image outside what this path covers (caller uses the host build).
@@ -174,6 +209,21 @@ int build_bokeh_cdf_device(const float *pixels, int width, int height, int nchan
         if (p) (void)hipFree(p);
     if (e != hipSuccess) { out.clear(); return static_cast<int>(e); }
     return 0;
+}
+
+// Cell records (tables.hpp) from the device-resident reference tables; dCells = records of the row CDF, records of the y
+// column CDFs, then the bounds in the same order ((gRow + y*gCol) * 5 dwords).  Identical to the host build in capi.cpp.
+int build_bokeh_cells_device(const float *dCdfRow, const int32_t *dRowIdx, const float *dCdfCol, const int32_t *dColIdx, int x, int y,
+                             int gRow, int gCol, uint32_t *dCells)
+{
+    const size_t nCells = static_cast<size_t>(gRow) + static_cast<size_t>(y) * gCol;
+    uint32_t *rowCells = dCells, *colCells = dCells + static_cast<size_t>(gRow) * 4;
+    uint32_t *rowBounds = dCells + nCells * 4, *colBounds = rowBounds + gRow;
+    hipLaunchKernelGGL(build_cells_kernel, dim3(static_cast<unsigned>(y) + 1u), dim3(256), 0, nullptr, dCdfRow, dRowIdx, dCdfCol, dColIdx, x, y,
+                       gRow, gCol, rowCells, colCells, rowBounds, colBounds);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return static_cast<int>(e);
 }
 
 }  // namespace zoic

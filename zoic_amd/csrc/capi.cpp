@@ -248,33 +248,42 @@ zoic_status upload_bokeh(zoic_camera *cam)
             const auto cellCount = [](int n) { int g = 16; while (g < n) g <<= 1; return g; };
             const int gRow = cellCount(im.y), gCol = cellCount(im.x);
             const size_t nCells = static_cast<size_t>(gRow) + y * static_cast<size_t>(gCol);
-            std::vector<uint32_t> cells(nCells * 5);          // records (4 dwords each), then the bounds (1 dword each)
-            uint32_t *bounds = cells.data() + nCells * 4;
-            // records of one CDF: cdf[n] non-decreasing, idx[n] pixel indices relative to `idxBase` (each < 65536)
-            const auto fill = [](const float *cdf, const int32_t *idx, int32_t idxBase, int n, int g, uint32_t *rec, uint32_t *bnd) {
-                int lo = 0, hi = 0;                            // both only move forward as the cell edge grows
-                for (int c = 0; c < g; ++c, rec += 4, ++bnd) {
-                    const float lower = static_cast<float>(c) / static_cast<float>(g), upper = static_cast<float>(c + 1) / static_cast<float>(g);
-                    while (lo < n && cdf[lo] <= lower) ++lo;   // lo = #{cdf <= lower}
-                    if (hi < lo) hi = lo;
-                    while (hi < n && cdf[hi] < upper) ++hi;    // hi = #{cdf <  upper}
-                    const float inf = INFINITY;
-                    const float a = lo < n ? cdf[lo] : inf, b = lo + 1 < n ? cdf[lo + 1] : inf;
-                    uint32_t id[3];
-                    for (int k = 0; k < 3; ++k) id[k] = static_cast<uint32_t>(idx[std::min(lo + k, n - 1)] - idxBase) & 0xffffu;
-                    std::memcpy(rec + 0, &a, 4);
-                    std::memcpy(rec + 1, &b, 4);
-                    rec[2] = id[0] | (id[1] << 16);
-                    rec[3] = id[2] | ((hi - lo > 2) ? 0x80000000u : 0u);
-                    *bnd = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
-                }
-            };
-            fill(im.cdfRow.data(), im.rowIndices.data(), 0, im.y, gRow, cells.data(), bounds);
-            for (size_t r = 0; r < y; ++r)
-                fill(im.cdfColumn.data() + r * im.x, im.columnIndices.data() + r * im.x, static_cast<int32_t>(r * im.x), im.x, gCol,
-                     cells.data() + (static_cast<size_t>(gRow) + r * gCol) * 4, bounds + gRow + r * gCol);
-            ZOIC_HIP(cam->dBokehCells.reserve(cells.size()));
-            ZOIC_HIP(hipMemcpy(cam->dBokehCells.ptr, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            // records (4 dwords each), then the bounds (1 dword each); built on the GPU from the tables uploaded above
+            // (one lane per cell), ZOIC_CELLS_HOST=1 keeps the host build for A/B -- both produce identical words
+            ZOIC_HIP(cam->dBokehCells.reserve(nCells * 5));
+            const char *envHost = std::getenv("ZOIC_CELLS_HOST");
+            if (!(envHost && envHost[0] == '1')) {
+                const int rc = build_bokeh_cells_device(cam->dCdfRow.ptr, cam->dRowIdx.ptr, cam->dCdfColumn.ptr, cam->dColIdx.ptr, im.x, im.y,
+                                                        gRow, gCol, cam->dBokehCells.ptr);
+                if (rc != 0) { g_lastError = "bokeh cell-record kernel failed"; return ZOIC_ERR_HIP; }
+            } else {
+                std::vector<uint32_t> cells(nCells * 5);
+                uint32_t *bounds = cells.data() + nCells * 4;
+                // records of one CDF: cdf[n] non-decreasing, idx[n] pixel indices relative to `idxBase` (each < 65536)
+                const auto fill = [](const float *cdf, const int32_t *idx, int32_t idxBase, int n, int g, uint32_t *rec, uint32_t *bnd) {
+                    int lo = 0, hi = 0;                            // both only move forward as the cell edge grows
+                    for (int c = 0; c < g; ++c, rec += 4, ++bnd) {
+                        const float lower = static_cast<float>(c) / static_cast<float>(g), upper = static_cast<float>(c + 1) / static_cast<float>(g);
+                        while (lo < n && cdf[lo] <= lower) ++lo;   // lo = #{cdf <= lower}
+                        if (hi < lo) hi = lo;
+                        while (hi < n && cdf[hi] < upper) ++hi;    // hi = #{cdf <  upper}
+                        const float inf = INFINITY;
+                        const float a = lo < n ? cdf[lo] : inf, b = lo + 1 < n ? cdf[lo + 1] : inf;
+                        uint32_t id[3];
+                        for (int k = 0; k < 3; ++k) id[k] = static_cast<uint32_t>(idx[std::min(lo + k, n - 1)] - idxBase) & 0xffffu;
+                        std::memcpy(rec + 0, &a, 4);
+                        std::memcpy(rec + 1, &b, 4);
+                        rec[2] = id[0] | (id[1] << 16);
+                        rec[3] = id[2] | ((hi - lo > 2) ? 0x80000000u : 0u);
+                        *bnd = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
+                    }
+                };
+                fill(im.cdfRow.data(), im.rowIndices.data(), 0, im.y, gRow, cells.data(), bounds);
+                for (size_t r = 0; r < y; ++r)
+                    fill(im.cdfColumn.data() + r * im.x, im.columnIndices.data() + r * im.x, static_cast<int32_t>(r * im.x), im.x, gCol,
+                         cells.data() + (static_cast<size_t>(gRow) + r * gCol) * 4, bounds + gRow + r * gCol);
+                ZOIC_HIP(hipMemcpy(cam->dBokehCells.ptr, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
             B.rowCells = cam->dBokehCells.ptr;
             B.colCells = cam->dBokehCells.ptr + static_cast<size_t>(gRow) * 4;
             B.rowBounds = cam->dBokehCells.ptr + nCells * 4;

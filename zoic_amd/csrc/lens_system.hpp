@@ -80,6 +80,10 @@ struct BokehCdf {
 // 0 = ok, -1 = image not covered (dimension > 4096 or < 2: use BokehCdf::build), > 0 = hipError_t
 int build_bokeh_cdf_device(const float *pixels, int width, int height, int nchannels, BokehCdf &out);
 
+// bokeh_cdf.hip: the cell records of tables.hpp built from the device-resident reference tables (0 = ok, else hipError_t)
+int build_bokeh_cells_device(const float *dCdfRow, const int32_t *dRowIdx, const float *dCdfCol, const int32_t *dColIdx, int x, int y,
+                             int gRow, int gCol, uint32_t *dCells);
+
 // minimal .pfm reader for bokehPath (the reference loads through Arnold's texture system, absent here)
 bool read_pfm(const std::string &path, std::vector<float> &pixels, int &w, int &h, int &nc);
 
