@@ -209,7 +209,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                 }
                 fresh = false;
                 V2 lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
-#ifdef ZOIC_EXP_DOUBLE_SAMPLE
+#ifdef ZOIC_EXP_DOUBLE_SAMPLE   // marginal-cost experiments (tools/ab_libs.sh): run a stage twice, time the difference
                 { const V2 l2 = lens_sample<STRICT>(T, B, bokehLds, u + lens.x * 0.0f, v + lens.y * 0.0f); lens.x += l2.x * 0.0f; lens.y += l2.y * 0.0f; }
 #endif
                 // the dead-pixel shortcut needs a finite first sample (NaN*0 would differ from later tries)
@@ -276,11 +276,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             if constexpr (NS > 0) {
                 // the predicated trace does not keep the partial state of a failed ray; a ray that FINISHES failed
                 // (out of tries) gets it from the branchy trace, which stops at the failing interface
-#ifdef ZOIC_EXP_NO_PARTIAL
-                if (false) {
-#else
                 if (cand && !ok && tries > static_cast<uint32_t>(kMaxTries)) {
-#endif
                     uint32_t ignored = 0;
                     o = oStart; d = dStart;
                     if constexpr (STRICT) (void)trace_lens_strict(T, o, d, ignored);
