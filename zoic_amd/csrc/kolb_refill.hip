@@ -10,17 +10,20 @@
 //     rank     = mbcnt(freeMask)             -- exclusive prefix sum: my slot among the free lanes
 //     mine     = cursor + rank               -- consecutive samples go to the free lanes (loads stay contiguous)
 //     cursor  += popcount(freeMask)          -- wave-uniform, lives in an SGPR; no atomics, no LDS, no barriers
-// so vignetted rays never hold finished lanes hostage, whatever the reject rate.  The cursor walks a 1024-sample
-// chunk claimed with one atomicAdd on a global work cursor: waves that drew cheap image regions simply claim more
-// chunks, so the frame's heavily vignetted corners cannot unbalance the chip and the grid size need not match the
-// true residency.  Retry streams are per ray (keyed by the global ray index), hence the result of every ray is
-// independent of which lane/pass/wave evaluated it -- the strict instantiation is bit-identical to the simple
-// one-sample-per-lane kernel and to the CPU oracle.
+// so vignetted rays never hold finished lanes hostage, whatever the reject rate.  The cursor walks a chunk (64 ... 1024
+// samples by batch size, 512 on a 4K x 16spp frame) claimed with one atomicAdd on one of eight partition cursors: waves
+// that drew cheap image regions simply claim more chunks, so the frame's heavily vignetted corners cannot unbalance the
+// chip and the grid size need not match the true residency.  Retry streams are per ray (keyed by the global ray index),
+// hence the result of every ray is independent of which lane/pass/wave evaluated it -- the strict instantiation is
+// bit-identical to the simple one-sample-per-lane kernel and to the CPU oracle.
 //
-// Tables: the lens prescription + LUT arrive by value (SGPRs via s_load, see tables.hpp); bokeh CDFs are searched
-// through the 16-ary pyramid (device_search.hpp).  Samples: one global_load_dwordx4 per refilled lane.  Rays: one
-// 32-byte record per ray (two 16-byte stores), written by the lane that finished it -- a whole sector per lane, so
-// the scattered completion order causes no partial-line write-backs.
+// Tables: the lens prescription + LUT arrive by value (SGPRs via s_load, see tables.hpp); a bokeh lens sample is one LDS
+// cell record + one global cell record (device_search.hpp; the 16-ary pyramid only for images without records).
+// Samples: a 64-entry prefetch window per wave, one global_load_dwordx4 per lane per pass, handed to refilled lanes with
+// ds_bpermute.  Rays: one 32-byte record per ray, parked in LDS by the finishing lane and written before the next trace
+// as whole sectors (flush_parked_records) -- the scattered completion order causes no partial-line write-backs.
+// Pass order (vmcnt is one in-order counter, see below): refill -> candidate search (draws, interface-0 test) ->
+// window prefetch + record flush -> trace -> finish (park).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -33,8 +36,8 @@ namespace zoic {
 
 // Register budgets.  SGPRs: a 256-lane workgroup is admitted per CU up to floor(800 / (ceil(sgpr/16)*16 + 16)) times
 // (MI355X_MICROARCH.md): 106 SGPRs -> 6 workgroups, <= 96 -> 7; capping at 94 measured +4.5 % on C3.  VGPRs: the fast
-// instantiations need 73 (72 + the SGPR-spill register), one over the 7-waves-per-SIMD line (512 / 7 -> 72); asking
-// for 7 waves costs a few spilled dwords and measured +4 % on C3.  The strict instantiations (127-137 VGPRs, f64
+// instantiations needed 73 (72 + the SGPR-spill register), one over the 7-waves-per-SIMD line (512 / 7 -> 72); with the
+// per-lane counters moved to SGPRs they fit 71 and asking for 7 waves measured +2.6 % on C3.  The strict instantiations (127-137 VGPRs, f64
 // intermediates) are held to 128 = 4 waves per SIMD (3 otherwise): +6-8 % (5 waves = 96 VGPRs spills too much: -12 %).
 #ifndef ZOIC_REFILL_ATTR_STRICT
 #define ZOIC_REFILL_ATTR_STRICT __attribute__((amdgpu_num_sgpr(94), amdgpu_waves_per_eu(4, 4)))
