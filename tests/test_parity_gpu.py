@@ -352,3 +352,28 @@ def test_bokeh_cell_records_exact_on_dense_cells(gpu, oracle_lib, monkeypatch, s
     g, r = got["planes"], ref["planes"]
     same = (bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))
     assert same.all(), "%d rays differ" % (~same.all(0)).sum()
+
+
+def test_launches_in_flight_on_several_streams(gpu):
+    """One camera, 24 batches of different sizes queued round-robin on 4 HIP streams before anything is waited for: every
+    launch owns its set of work cursors (a ring of 64), so each batch must come out exactly as when it runs alone."""
+    import torch
+    cam = ZoicCamera(0)
+    cam.set_bokeh_image(hexagon_bokeh())
+    cam.update(**camera_params("C3"))
+    c = CONFIGS["C3"]
+    sizes = [200_000 + 37_111 * i for i in range(24)]
+    bases = [c["width"] * 700 * c["spp"] + 1_000_003 * i for i in range(24)]
+    samples = [cam.generate_samples(n, c["width"], c["height"], c["spp"], seed=3, ray_index_base=b) for n, b in zip(sizes, bases)]
+    torch.cuda.synchronize()
+    alone = []
+    for s, b in zip(samples, bases):
+        alone.append(cam.create_rays(s, ray_index_base=b)["rays"].clone())
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [dict(rays=torch.empty((n, 8), dtype=torch.float32, device="cuda")) for n in sizes]
+    for i, (s, b) in enumerate(zip(samples, bases)):
+        cam.create_rays(s, ray_index_base=b, out=outs[i], stream=streams[i % 4].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(24):
+        assert torch.equal(outs[i]["rays"].view(torch.int32), alone[i].view(torch.int32)), "batch %d differs" % i
