@@ -377,3 +377,22 @@ def test_launches_in_flight_on_several_streams(gpu):
     torch.cuda.synchronize()
     for i in range(24):
         assert torch.equal(outs[i]["rays"].view(torch.int32), alone[i].view(torch.int32)), "batch %d differs" % i
+
+
+@pytest.mark.parametrize("lens,focal,fstop", [("mori_f2.8.dat", 5.0, 2.8), ("mori_f2.8.dat", 3.0, 5.6),
+                                             ("triplet_f2.5.dat", 5.0, 2.5), ("triplet_f2.5.dat", 3.5, 8.0)])
+@pytest.mark.parametrize("lut", [True, False])
+def test_strict_bit_exact_other_prescriptions(gpu, oracle_lib, lens, focal, fstop, lut):
+    """The shipped prescriptions the BASELINE configs do not use (7 and 11 interfaces; F_1.6_PETZVAL and F_5.0_TELEPHOTO have no stop
+    row and are rejected with ZOIC_ERR_NO_APERTURE, tests/test_host_tables.py), with and without the exit-pupil LUT, strict mode,
+    bit-exact vs the oracle."""
+    p = dict(camera_params("C2"), lensDataPath=lens_path(lens), focalLength=focal, fStop=fstop, kolbSamplingLUT=lut)
+    cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+    cam.update(**p); oc.update(**p)
+    n = 1 << 15
+    for where in (0.5, 0.04):
+        s, base = slab("C2", n, where)
+        got = cam.create_rays(s, ray_index_base=base)
+        ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=1, ray_index_base=base), threads=8)
+        assert_bit_exact(got, ref)
+    assert cam.counters() == oc.counters()
