@@ -287,17 +287,24 @@ CUSTOM_LENS_14 = ("80.0\t3.0\t1.6\t40.0\n200.0\t1.0\t0.0\t40.0\n60.0\t3.0\t1.65\
                   "300.0\t3.0\t1.65\t28.0\n-120.0\t1.0\t0.0\t28.0\n500.0\t2.5\t1.6\t28.0\n-200.0\t60.0\t0.0\t28.0\n")
 
 
-@pytest.mark.parametrize("text", [CUSTOM_LENS_5, CUSTOM_LENS_14])
-def test_generic_interface_count_path(gpu, oracle_lib, text):
-    """Lenses whose interface count has no unrolled instantiation (not 7..12) run the rolled generic trace: strict must
-    still be bit-exact, fast within tolerance."""
+# the first 10 rows of CUSTOM_LENS_14 (back focus on the last one), and the same with its cemented doublet made a singlet
+CUSTOM_LENS_10 = ("80.0\t3.0\t1.6\t40.0\n200.0\t1.0\t0.0\t40.0\n60.0\t3.0\t1.65\t36.0\n150.0\t1.0\t0.0\t36.0\n45.0\t4.0\t1.7\t30.0\n"
+                  "90.0\t6.0\t0.0\t28.0\n0\t6.0\t0\t20.0\n-90.0\t2.0\t1.6\t24.0\n120.0\t4.0\t1.7\t26.0\n-60.0\t60.0\t0.0\t26.0\n")
+CUSTOM_LENS_9 = ("80.0\t3.0\t1.6\t40.0\n200.0\t1.0\t0.0\t40.0\n60.0\t3.0\t1.65\t36.0\n150.0\t1.0\t0.0\t36.0\n45.0\t4.0\t1.7\t30.0\n"
+                 "90.0\t6.0\t0.0\t28.0\n0\t6.0\t0\t20.0\n-90.0\t6.0\t1.6\t24.0\n-60.0\t60.0\t0.0\t26.0\n")
+
+
+@pytest.mark.parametrize("text,count", [(CUSTOM_LENS_5, 5), (CUSTOM_LENS_14, 14), (CUSTOM_LENS_9, 9), (CUSTOM_LENS_10, 10)])
+def test_generic_interface_count_path(gpu, oracle_lib, text, count):
+    """Lenses whose interface count has no unrolled instantiation (not 7..12) run the rolled generic trace; 9 and 10 are
+    the unrolled instantiations no shipped prescription reaches.  Strict must be bit-exact, fast within tolerance."""
     kw = dict(focalLength=5.0, fStop=2.8, focalDistance=150.0)
     cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
     cam.set_lens_text(text)
     oc.set_lens_text(text)
     cam.update(**kw)
     oc.update(**kw)
-    assert cam.info()["lensCount"] in (5, 14)
+    assert cam.info()["lensCount"] == count
     n = 1 << 16
     s, base = slab("C2", n, 0.45)
     ref = oc.create_rays(s, rng_states=ray_rng_states(n, 1, base), threads=8)
