@@ -232,6 +232,50 @@ def test_full_frame_properties_c3(gpu, oracle_lib):
     assert 0.0 <= frac < 0.01
 
 
+@pytest.mark.parametrize("cfg,frac_lo,frac_hi", [("C2", 0.10, 0.30), ("C4", 0.0, 0.01), ("C5", 0.0, 1.0)])
+def test_full_frame_properties_other_configs(gpu, oracle_lib, cfg, frac_lo, frac_hi):
+    """The other Kolb configs at their full BASELINE sizes (C2 16.6 M, C4 265 M, C5 2.1 G samples = 102 GB of samples +
+    records), fast and strict: every ray accounted for once, zero weight <=> out of tries, accepted rays have unit
+    direction heading to -z, a slab of the device result equals the host-buffer path bit for bit and (strict) the oracle."""
+    import torch
+    c = CONFIGS[cfg]
+    n = ray_count(cfg)
+    cam, oc = make_pair(oracle_lib, cfg)
+    samples = cam.generate_samples(n, c["width"], c["height"], c["spp"], seed=1)
+    out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device="cuda"))
+    for mode in (PRECISION_STRICT, PRECISION_FAST):
+        cam.set_precision(mode)
+        cam.reset_counters()
+        res = cam.create_rays(samples, out=out)
+        torch.cuda.synchronize()
+        cnt = cam.counters()
+        assert cnt["succesRays"] + cnt["vignettedRays"] == n
+        rays = res["rays"]
+        w = rays[:, 6]
+        fl = rays[:, 7].view(torch.int32)
+        tries, lut_miss = (fl >> 1) & 31, (fl >> 6) & 1
+        zero = w == 0
+        assert int(zero.sum().item()) == cnt["vignettedRays"]
+        assert bool((zero == ((tries == 26) | (lut_miss == 1))).all().item())   # out of tries (zoic.cpp:1951) or outside the LUT
+        del tries, lut_miss, fl
+        step = max(1, n // (1 << 26))            # unit-direction check on a strided sample of at most 64 M rays
+        sub = rays[::step]
+        live = sub[:, 6] != 0
+        d = sub[:, 3:6][live]
+        assert float(((d * d).sum(1).sqrt() - 1).abs().max().item()) < 2e-5
+        assert bool((d[:, 2] < 0).all().item())
+        del d, live, sub, zero
+        k = 1 << 15
+        base = (c["height"] // 3) * c["width"] * c["spp"]
+        host = cam.create_rays(samples[base:base + k].cpu().numpy(), ray_index_base=base)
+        dev = rays[base:base + k].cpu().numpy()
+        assert np.array_equal(bits(host["planes"]), bits(np.ascontiguousarray(dev[:, :7].T)))
+        if mode == PRECISION_STRICT:
+            ref = oc.create_rays(samples[base:base + k].cpu().numpy(), rng_states=ray_rng_states(k, 1, base), threads=8)
+            assert_bit_exact(host, ref)
+    assert frac_lo <= cnt["vignettedRays"] / n <= frac_hi
+
+
 def test_gpu_lut_build_equals_host_lut_build(gpu, oracle_lib, monkeypatch):
     """node_update traces the 3.2 M exit-pupil probes on the GPU by default; ZOIC_LUT_HOST=1 keeps them on the host.
     Both must give the oracle's table."""
