@@ -95,7 +95,10 @@ def test_strict_thinlens_variants(gpu, oracle_lib):
     n = 1 << 15
     for kw in (dict(opticalVignettingDistance=5.0), dict(opticalVignettingDistance=5.0, opticalVignettingRadius=0.4),
                dict(useDof=False), dict(useImage=True, bokehPath="procedural:hexagon256", opticalVignettingDistance=3.0),
-               dict(exposureControl=0.7)):
+               dict(exposureControl=0.7),
+               dict(opticalVignettingDistance=30.0),                       # nearly every ray runs out of tries
+               dict(opticalVignettingDistance=1.0, exposureControl=-0.5),  # a few retries per wave: refill next to fresh rays
+               dict(useImage=True, bokehPath="procedural:hexagon256", opticalVignettingDistance=12.0, opticalVignettingRadius=1.5)):
         cam, oc = make_pair(oracle_lib, "C1", **kw)
         s, base = slab("C1", n, 0.7)
         got = cam.create_rays(s, ray_index_base=base)

@@ -16,8 +16,6 @@ constexpr int kRefillBlock = 256;
 constexpr int kWavesPerBlock = kRefillBlock / 64;
 constexpr uint32_t kLutLdsWords = 2 * kLutEntries;  // (maxScale, centroid.x) pairs at the start of the dynamic LDS
 constexpr uint32_t kMinSearching = 16;  // the candidate search goes on while at least this many lanes of the wave are looking
-constexpr uint32_t kChunkRays = 1024;  // most samples a wave claims per atomic on a work cursor (16 passes of fresh work);
-                                       // the launcher picks the actual size from a claim budget (kolb_refill.hip)
 
 template <bool STRICT>
 __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v)

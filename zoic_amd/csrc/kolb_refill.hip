@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "kolb_device.hpp"
+#include "work_cursor.hpp"
 
 #pragma STDC FP_CONTRACT OFF
 
@@ -59,22 +60,6 @@ __device__ unsigned long long g_regionCycles[8];
 #define ZOIC_RT_FLUSH
 #endif
 
-// LDS -> HBM for the records a wave parked in its last pass.  `stage` holds the 64 record slots as 128 consecutive
-// 16-byte pieces, `stageIdx` the ray index per slot (0xffffffff: empty).  Lane j writes piece j, then piece 64 + j:
-// neighbouring lanes write the two halves of one record, and rays refilled together (consecutive indices in lane order)
-// mostly finish together, so one store instruction covers whole 32-byte sectors in long contiguous runs instead of 64
-// half-sectors at a 32-byte stride.
-__device__ __forceinline__ void flush_parked_records(RayRecord *out, const float4 *stage, const uint32_t *stageIdx, uint32_t lane)
-{
-#pragma unroll
-    for (uint32_t h = 0; h < 2; ++h) {
-        const uint32_t j = lane + 64u * h;
-        const uint32_t id = stageIdx[j >> 1];
-        const float4 piece = stage[j];
-        if (id != 0xffffffffu) reinterpret_cast<float4 *>(out + id)[j & 1u] = piece;
-    }
-}
-
 template <bool STRICT, int NS>
 __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
                                                  const uint4 *__restrict__ rngStates, uint64_t rayBase, uint32_t n,
@@ -103,7 +88,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     float4 *stage = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords) + (threadIdx.x >> 6) * 144u;  // 128 pieces + 64 indices
     uint32_t *stageIdx = reinterpret_cast<uint32_t *>(stage + 128);
     bool parked = false;   // wave-uniform: records of the last pass wait in LDS
-    // wave-uniform work window [next, end): a chunk of kChunkRays consecutive samples claimed from the global cursor
+    // wave-uniform work window [next, end): a chunk of chunkRays consecutive samples claimed from a partition cursor (work_cursor.hpp)
     uint32_t next = 0, end = 0;
     bool exhausted = false;
     uint32_t part = blockIdx.x % kCursorParts, partsTried = 0;   // the partition cursor this wave claims from (kernels.hpp)
@@ -125,23 +110,10 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         // ---- refill the free lanes from the work window (ballot + prefix sum) ---------------------------------
         unsigned long long freeMask = __ballot(!active);
         while (freeMask != 0ull && !exhausted) {
-            if (next >= end) {  // claim the next chunk: one atomic per chunkRays samples per wave, on the partition's cursor
-                uint64_t begin = n;
-                while (partsTried < kCursorParts) {
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(workCursor + part * kCursorPartStride, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c);
-                    begin = (static_cast<uint64_t>(part) * chunksPerPart + c) * chunkRays;
-                    if (c < chunksPerPart && begin < n) break;
-                    begin = n;                                   // this partition is used up: on to the next one, for good
-                    part = (part + 1u) % kCursorParts;
-                    ++partsTried;
-                }
-                if (begin >= n) { exhausted = true; break; }
-                next = static_cast<uint32_t>(begin);
-                end = (begin + chunkRays < n) ? static_cast<uint32_t>(begin + chunkRays) : n;
+            if (next >= end) {  // claim the next chunk: one atomic per chunkRays samples per wave (work_cursor.hpp)
+                if (!claim_chunk(workCursor, lane, part, partsTried, chunkRays, chunksPerPart, n, next, end)) { exhausted = true; break; }
             }
-            if (winBase != next) {  // first use of a chunk: the window has to be fetched in line (once per kChunkRays)
+            if (winBase != next) {  // first use of a chunk: the window has to be fetched in line (once per chunk)
                 const uint32_t wi = next + lane;
                 win = samples[wi < n ? wi : n - 1];
                 winBase = next;
@@ -349,25 +321,11 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;
     for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
         const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
-        hipError_t e = hipMemsetAsync(d_workCursor, 0, kCursorParts * kCursorPartStride * sizeof(unsigned int), st);  // same stream as the kernel: ordered
+        hipError_t e = reset_work_cursors(d_workCursor, st);
         if (e != hipSuccess) return static_cast<int>(e);
-        // persistent waves: enough workgroups to fill every wave slot of 256 CUs (8 x 256 lanes per CU); late or
-        // surplus workgroups find the cursor exhausted and retire at once, so residency need not be known exactly
-        const uint64_t tiles = (m + 63) / 64;
-        const uint64_t wantBlocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-        const unsigned grid = static_cast<unsigned>(wantBlocks < 2048 ? (wantBlocks ? wantBlocks : 1) : 2048);
-        // chunk = what one atomic claims.  Claims on ONE address are served by the L2 at about one per 12 ns (measured:
-        // 518 K claims of 256 samples took 6.3 ms on a frame that otherwise takes 4.0; 130 K claims of 64 took 1.75 ms on
-        // an 8.3 M-sample batch that takes 0.63 ms with 256), so the batch is cut into kCursorParts partitions with a
-        // cursor each and a launch gets a budget of ~32 K claims per cursor: 512-sample chunks on a 4K x 16spp frame.
-        // Below 256 samples a wave changes chunk (an exposed atomic + window fetch) every few passes: not worth it unless
-        // the batch is small.  ZOIC_CHUNK_RAYS overrides the rule (experiments).
-        uint64_t chunk = (m / (32768ull * kCursorParts) + 63) / 64 * 64;
-        if (chunk < 256 && m >= (4ull << 20)) chunk = 256;
-        static const uint32_t chunkOverride = [] { const char *e = std::getenv("ZOIC_CHUNK_RAYS"); return e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }();
-        const uint32_t chunkRays = chunkOverride ? chunkOverride : static_cast<uint32_t>(chunk < 64 ? 64 : (chunk > kChunkRays ? kChunkRays : chunk));
-        const uint64_t totalChunks = (m + chunkRays - 1) / chunkRays;
-        const uint32_t chunksPerPart = static_cast<uint32_t>((totalChunks + kCursorParts - 1) / kCursorParts);
+        const unsigned grid = persistent_grid(m, kWavesPerBlock);
+        const WorkGrain grain = work_grain(m);
+        const uint32_t chunkRays = grain.chunkRays, chunksPerPart = grain.chunksPerPart;
         RayRecord *o = out + done;
         static const uint32_t minSearching = [] { const char *e = std::getenv("ZOIC_MIN_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kMinSearching; }();
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;

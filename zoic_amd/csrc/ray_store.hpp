@@ -47,4 +47,20 @@ __device__ __forceinline__ void store_ray_records_wave(RayRecord *out, uint64_t 
     __builtin_amdgcn_wave_barrier();
 }
 
+// LDS -> HBM for the records a wave parked in its last pass.  `stage` holds the 64 record slots as 128 consecutive
+// 16-byte pieces, `stageIdx` the ray index per slot (0xffffffff: empty).  Lane j writes piece j, then piece 64 + j:
+// neighbouring lanes write the two halves of one record, and rays refilled together (consecutive indices in lane order)
+// mostly finish together, so one store instruction covers whole 32-byte sectors in long contiguous runs instead of 64
+// half-sectors at a 32-byte stride.
+__device__ __forceinline__ void flush_parked_records(RayRecord *out, const float4 *stage, const uint32_t *stageIdx, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        const uint32_t j = lane + 64u * h;
+        const uint32_t id = stageIdx[j >> 1];
+        const float4 piece = stage[j];
+        if (id != 0xffffffffu) reinterpret_cast<float4 *>(out + id)[j & 1u] = piece;
+    }
+}
+
 }  // namespace zoic
