@@ -450,3 +450,26 @@ def test_strict_bit_exact_other_prescriptions(gpu, oracle_lib, lens, focal, fsto
         ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=1, ray_index_base=base), threads=8)
         assert_bit_exact(got, ref)
     assert cam.counters() == oc.counters()
+
+
+@pytest.mark.parametrize("kw", [dict(opticalVignettingDistance=2.0), dict(opticalVignettingDistance=8.0, opticalVignettingRadius=1.2),
+                                dict(useImage=True, bokehPath="procedural:hexagon256", opticalVignettingDistance=4.0)])
+def test_fast_mode_thinlens_vignetting_within_tolerance(gpu, oracle_lib, kw):
+    """The fast arithmetic of the thin-lens refill kernel (rsq normalisation, f32 disk mapping, v_sqrt in the vignetting
+    test): same tolerances as the Kolb fast mode -- direction RMSE < 1e-5 on rays whose accept/reject history agrees,
+    decision flips below FLIP_TOL."""
+    cam, oc = make_pair(oracle_lib, "C1", **kw)
+    cam.set_precision(PRECISION_FAST)
+    n = 1 << 17
+    s, base = slab("C1", n, 0.6)
+    got = cam.create_rays(s, ray_index_base=base)
+    ref = oc.create_rays(s, rng_states=ray_rng_states(n, 1, base), threads=8)
+    same = got["flags"] == ref["flags"]
+    assert 1.0 - float(same.mean()) < FLIP_TOL
+    live = same & (ref["weight"] != 0)
+    assert live.sum() > 1000
+    dd = got["dir"][:, live].astype(np.float64) - ref["dir"][:, live]
+    do = got["origin"][:, live].astype(np.float64) - ref["origin"][:, live]
+    assert float(np.sqrt((dd ** 2).sum(0).mean())) < DIR_RMSE_TOL
+    assert float(np.sqrt((do ** 2).sum(0).mean())) < 1e-5
+    assert (ref["flags"] & 1).mean() > 0.05          # the retry loop really ran

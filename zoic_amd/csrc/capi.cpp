@@ -548,7 +548,8 @@ zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d
         break;
     case ZOIC_THINLENS:
         rc = launch_thin_rays(cam->thin, bokeh_tables(cam), d_samples, d_rng_states, ray_index_base, n, planes, cam->dCounters,
-                              cam->dWorkCursor + (cam->nextCursor++ % kWorkCursors) * kCursorStride, stream);
+                              cam->dWorkCursor + (cam->nextCursor++ % kWorkCursors) * kCursorStride,
+                              cam->precision == ZOIC_PRECISION_FAST, stream);
         break;
     default:
         return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");

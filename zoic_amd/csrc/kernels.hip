@@ -292,15 +292,16 @@ int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const flo
 }
 
 int launch_thin_refill(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng, uint64_t rayBase,
-                       uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, void *stream);
+                       uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, bool fast, void *stream);
 
 int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, void *stream)
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, bool fast,
+                     void *stream)
 {
     if (n == 0) return 0;
     static const bool simpleThin = [] { const char *e = std::getenv("ZOIC_THIN_VARIANT"); return e && std::string(e) == "simple"; }();
     if (table.useDof && table.ovDistance > 0.0f && !simpleThin)   // the retry loop of zoic.cpp:1804-1819 can run
-        return launch_thin_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, stream);
+        return launch_thin_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, fast, stream);
     const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
     hipLaunchKernelGGL(thin_rays_kernel, dim3(grid_for(n)), dim3(kBlock), ldsWords * sizeof(float), static_cast<hipStream_t>(stream),
                        table, bokeh, reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,

@@ -36,7 +36,8 @@ int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const flo
 // persistent-wave refill kernel of thin_refill.hip runs, otherwise the streaming kernel; ZOIC_THIN_VARIANT=simple
 // forces the streaming kernel (A/B).
 int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, void *stream);
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, bool fast,
+                     void *stream);   // fast: only the refill kernel has a fast arithmetic variant (the streaming kernel is HBM-bound)
 
 // synthetic camera samples: id=(py*W+px)*spp+s, pcg-hashed jitter and lens samples
 int launch_generate_samples(float *d_samples, uint64_t rayBase, uint64_t n, uint32_t width, uint32_t height, uint32_t spp,

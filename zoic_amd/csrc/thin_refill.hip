@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_search.hpp"
+#include "fast_optics.hpp"
 #include "kernels.hpp"
 #include "optics.hpp"
 #include "ray_store.hpp"
@@ -36,6 +37,10 @@ __device__ __forceinline__ bool vignet_pass(const ThinTable &T, V3 origin, V3 di
     return fabsf(hyp) < T.apertureRadius * T.ovRadius;
 }
 
+// FAST (zoic_camera_set_precision): f32 rsq normalisation, the f32 disk mapping and v_sqrt in the vignetting test instead
+// of the reference's correctly rounded divides and square roots -- ~75 instead of ~140 instructions per redraw; direction
+// error ~1e-7, decision flips at the vignetting boundary only (tests/test_parity_gpu.py).  STRICT is bit-exact.
+template <bool FAST>
 __global__ __launch_bounds__(kThinBlock) void thin_refill_kernel(const ThinTable T, const BokehTables B, const float4 *__restrict__ samples,
                                                                  const uint4 *__restrict__ rngStates, uint64_t rayBase, uint32_t n,
                                                                  RayRecord *__restrict__ out, DeviceCounters *counters,
@@ -115,13 +120,24 @@ __global__ __launch_bounds__(kThinBlock) void thin_refill_kernel(const ThinTable
         bool trying = active;
         for (;;) {
             if (trying) {
-                V2 lens = useImage ? (rowCells ? bokeh_sample_cells<true>(B, rowCells, T.bokehW, T.bokehH, u, v)
+                V2 lens = useImage ? (rowCells ? bokeh_sample_cells<!FAST>(B, rowCells, T.bokehW, T.bokehH, u, v)
                                                : bokeh_sample_device(B, T.bokehW, T.bokehH, u, v))
-                                   : concentric_disk(u, v);
+                                   : (FAST ? concentric_disk_f32(u, v) : concentric_disk(u, v));
                 lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
                 const V3 origin{lens.x, lens.y, 0.0f};
-                V3 dir = normalize3(V3{fpx - origin.x, fpy - origin.y, fpz - origin.z});
-                const bool done = vignet_pass(T, origin, dir) || tries > static_cast<uint32_t>(kMaxTries);
+                V3 dir;
+                bool clear;
+                if constexpr (FAST) {
+                    const V3 q{fpx - origin.x, fpy - origin.y, fpz - origin.z};
+                    const float inv = frsq_fast(q.x * q.x + q.y * q.y + q.z * q.z);
+                    dir = V3{q.x * inv, q.y * inv, q.z * inv};
+                    const float px = dir.x * T.ovDistance - origin.x, py = dir.y * T.ovDistance - origin.y;
+                    clear = fsqrt_fast(px * px + py * py) < T.apertureRadius * T.ovRadius;
+                } else {
+                    dir = normalize3(V3{fpx - origin.x, fpy - origin.y, fpz - origin.z});
+                    clear = vignet_pass(T, origin, dir);
+                }
+                const bool done = clear || tries > static_cast<uint32_t>(kMaxTries);
                 if (done) {
                     float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;      // zoic.cpp:1824-1830
                     dir.z = dir.z * -1.0f;                                                   // zoic.cpp:1845
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(kThinBlock) void thin_refill_kernel(const ThinTable
 }  // namespace
 
 int launch_thin_refill(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng, uint64_t rayBase,
-                       uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, void *stream)
+                       uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, bool fast, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;   // 32-bit ray offsets inside the kernel; larger batches are split
@@ -173,10 +189,13 @@ int launch_thin_refill(const ThinTable &table, const BokehTables &bokeh, const f
         const WorkGrain grain = work_grain(m);
         const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
         const size_t ldsBytes = static_cast<size_t>(ldsWords) * sizeof(float) + kThinWaves * 144 * sizeof(float4);
-        hipLaunchKernelGGL(thin_refill_kernel, dim3(persistent_grid(m, kThinWaves)), dim3(kThinBlock), ldsBytes, st, table, bokeh,
-                           reinterpret_cast<const float4 *>(d_samples) + done, d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr,
-                           rayBase + done, static_cast<uint32_t>(m), out + done, d_counters, d_workCursor, ldsWords, grain.chunkRays,
-                           grain.chunksPerPart);
+#define ZOIC_LAUNCH_THIN(FAST_)                                                                                                  \
+    hipLaunchKernelGGL(thin_refill_kernel<FAST_>, dim3(persistent_grid(m, kThinWaves)), dim3(kThinBlock), ldsBytes, st, table, bokeh,  \
+                       reinterpret_cast<const float4 *>(d_samples) + done, d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr, \
+                       rayBase + done, static_cast<uint32_t>(m), out + done, d_counters, d_workCursor, ldsWords, grain.chunkRays,      \
+                       grain.chunksPerPart)
+        if (fast) ZOIC_LAUNCH_THIN(true); else ZOIC_LAUNCH_THIN(false);
+#undef ZOIC_LAUNCH_THIN
         e = hipGetLastError();
         if (e != hipSuccess) return static_cast<int>(e);
     }
