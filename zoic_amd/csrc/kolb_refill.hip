@@ -132,23 +132,26 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                 u = s.z; v = s.w;
                 tries = 0; lutMiss = 0; dead = false;
                 if (T.useLUT) {            // zoic.cpp:1891-1911: per-sample constants of the exit-pupil transform
-                    if constexpr (STRICT) {
-                        const float dist = fabsf(sqrtf(o0x * o0x + o0y * o0y));
-                        const float theta = static_cast<float>(atan2(static_cast<double>(o0y), static_cast<double>(o0x)));
-                        sn = fast_sin(theta);
-                        cs = fast_cos(theta);
-                        lutMiss = lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation) ? 0u : 1u;
-                    } else {
-                        const float dist = fsqrt_fast(o0x * o0x + o0y * o0y);
-                        const float theta = atan2f(o0y, o0x);
-                        sn = fast_sin_f32(theta);
-                        cs = fast_cos_f32(theta);
-                        lutMiss = lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation) ? 0u : 1u;
-                    }
+                    float dist;
+                    if constexpr (STRICT) dist = fabsf(sqrtf(o0x * o0x + o0y * o0y));
+                    else dist = fsqrt_fast(o0x * o0x + o0y * o0y);
+                    lutMiss = lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation) ? 0u : 1u;
                     // Outside the image circle the LUT entries are all zero (zoic.cpp:1403-1404 never grown): every try
                     // then shoots lens = (0,0).  With o0x != 0 and o0y != 0 the direction (0 - o0x, 0 - o0y, dirZ) is
                     // bit-identical for all 27 tries whatever the signs of the zeros, so one failed trace decides them all.
                     dead = (maxScale == 0.0f) && (translation == 0.0f) && (o0x != 0.0f) && (o0y != 0.0f);
+                    sn = 0.0f; cs = 1.0f;
+                    if (!dead) {           // the rotation of (0,0) needs no angle: dead pixels skip atan2 + sin + cos
+                        if constexpr (STRICT) {
+                            const float theta = static_cast<float>(atan2(static_cast<double>(o0y), static_cast<double>(o0x)));
+                            sn = fast_sin(theta);
+                            cs = fast_cos(theta);
+                        } else {
+                            const float theta = atan2f(o0y, o0x);
+                            sn = fast_sin_f32(theta);
+                            cs = fast_cos_f32(theta);
+                        }
+                    }
                 }
                 active = true; fresh = true;
             }
@@ -183,7 +186,13 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                     ++tries;
                 }
                 fresh = false;
-                V2 lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
+                // A dead pixel's first sample is multiplied by maxScale = 0 and offset by translation = 0: whatever finite
+                // point the sampler returns, the direction is (0 - o.x, 0 - o.y, dirZ) (o.x, o.y != 0).  Samples in [0,1)^2
+                // always give a finite point -- except the disk mapping's 0/0 at its centre -- so those skip the sampler.
+                const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
+                const bool skipSampler = first && dead && plainSample;
+                V2 lens{0.0f, 0.0f};
+                if (!skipSampler) lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
 #ifdef ZOIC_EXP_DOUBLE_SAMPLE   // marginal-cost experiments (tools/ab_libs.sh): run a stage twice, time the difference
                 { const V2 l2 = lens_sample<STRICT>(T, B, bokehLds, u + lens.x * 0.0f, v + lens.y * 0.0f); lens.x += l2.x * 0.0f; lens.y += l2.y * 0.0f; }
 #endif
