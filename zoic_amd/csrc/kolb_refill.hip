@@ -88,6 +88,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     float4 *stage = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords) + (threadIdx.x >> 6) * 144u;  // 128 pieces + 64 indices
     uint32_t *stageIdx = reinterpret_cast<uint32_t *>(stage + 128);
     bool parked = false;   // wave-uniform: records of the last pass wait in LDS
+    const bool memoryPhasesFirst = T.useImage != 0;
     // wave-uniform work window [next, end): a chunk of chunkRays consecutive samples claimed from a partition cursor (work_cursor.hpp)
     uint32_t next = 0, end = 0;
     bool exhausted = false;
@@ -107,6 +108,10 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
 
     for (;;) {
         ZOIC_RT_MARK(4)
+        // Wave priority (s_setprio; measured, same box): with the bokeh image on, waves wait half their cycles on the sampler's
+        // LDS -> global chain, and letting the waves that are in their memory phases issue first gets those loads out
+        // earlier (C3 +2 %); without it the launch is compute-dense and the waves inside the trace go first (C4 +3 %).
+        if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(1);
         // ---- refill the free lanes from the work window (ballot + prefix sum) ---------------------------------
         unsigned long long freeMask = __ballot(!active);
         while (freeMask != 0ull && !exhausted) {
@@ -241,6 +246,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         const V3 oStart = o, dStart = d;
         const bool firstTry = tries == 0;
         if (__ballot(cand) != 0ull) {
+            if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
             uint32_t tirTry = 0;   // 0/1: this try ended in total internal reflection
             if constexpr (NS > 0) {
                 if constexpr (STRICT) ok = trace_lens_strict_pred<NS>(T, o, d, tirTry, cand);
@@ -268,6 +274,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                 }
             }
         }
+        if (!memoryPhasesFirst) __builtin_amdgcn_s_setprio(0);
         // a ray is finished when a try got through, or when it is out of tries (loop exit of zoic.cpp:1927); a lane that
         // ran out at interface 0 must hand out the untouched (o, d) of its last sample -- the reference's partial state
         // (the predicated trace scribbles over the registers of lanes that ride along)
