@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <string>
 #include <cstring>
 
 #include "device_search.hpp"
