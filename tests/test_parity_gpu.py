@@ -4,6 +4,8 @@ STRICT mode is held to bit-exactness (integer flags AND every f32 plane); FAST m
 (direction RMSE < 1e-5 over rays with identical accept/try history and weight != 0, decision flips counted).
 Full-size runs are checked through size-independent properties.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -473,3 +475,45 @@ def test_fast_mode_thinlens_vignetting_within_tolerance(gpu, oracle_lib, kw):
     assert float(np.sqrt((dd ** 2).sum(0).mean())) < DIR_RMSE_TOL
     assert float(np.sqrt((do ** 2).sum(0).mean())) < 1e-5
     assert (ref["flags"] & 1).mean() > 0.05          # the retry loop really ran
+
+
+def test_strict_parameter_fuzz(gpu, oracle_lib):
+    """Machine-made cameras: every shipped prescription with a stop, focal length / f-stop / focus distance / sensor size /
+    exposure / LUT and DOF switches drawn at random (both lens models), 4096 samples each from a random place of the frame.
+    Strict mode must stay bit-identical to the oracle, counters included; parameter sets the reference aborts on must be
+    rejected with the same error class on both sides."""
+    from hypothesis import given, settings, HealthCheck, strategies as st
+    lenses = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat", "triplet_f2.5.dat", "mori_f2.8.dat"]
+
+    @settings(max_examples=int(os.environ.get("ZOIC_FUZZ_EXAMPLES", "40")), deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.sampled_from(lenses), st.floats(1.0, 20.0, width=32), st.floats(1.0, 22.0, width=32), st.floats(20.0, 2000.0, width=32),
+           st.floats(1.0, 7.0, width=32), st.floats(-2.0, 2.0, width=32), st.booleans(), st.booleans(), st.sampled_from([RAYTRACED, RAYTRACED, THINLENS]),
+           st.floats(0.0, 6.0, width=32), st.floats(0.02, 0.98), st.integers(0, 2 ** 20))
+    def run(lens, focal, fstop, focus, sensor_w, exposure, lut, dof, model, ov, where, seed):
+        p = dict(lensModel=model, lensDataPath=lens_path(lens), focalLength=focal, fStop=fstop, focalDistance=focus, sensorWidth=sensor_w,
+                 sensorHeight=sensor_w / 1.5, exposureControl=exposure, kolbSamplingLUT=lut, useDof=dof, opticalVignettingDistance=ov,
+                 opticalVignettingRadius=1.0, useImage=False)
+        cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+        perr = oerr = None
+        try:
+            cam.update(**p)
+        except Exception as e:
+            perr = getattr(e, "status_name", type(e).__name__).replace("ZOIC_ERR_", "")
+        try:
+            oc.update(**p)
+        except oracle_lib.OracleError as e:
+            oerr = oracle_lib.ERR_NAMES[e.code]
+        assert perr == oerr, (p, perr, oerr)
+        if perr is not None:
+            return
+        cam.set_seed(seed)
+        n = 4096
+        s, base = slab("C2", n, where)
+        got = cam.create_rays(s, ray_index_base=base)
+        ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=seed, ray_index_base=base), threads=4)
+        assert np.array_equal(got["flags"], ref["flags"]), p
+        g, r = got["planes"], ref["planes"]
+        same = (bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))
+        assert same.all(), (p, int((~same.all(0)).sum()))
+        assert cam.counters() == oc.counters(), p
+    run()
