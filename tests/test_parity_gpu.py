@@ -557,3 +557,31 @@ def test_fast_parameter_fuzz(gpu, oracle_lib):
         worst["flip"] = max(worst["flip"], flip)
     run()
     print("fast-mode fuzz: worst direction RMSE %.3g, worst flip fraction %.3g" % (worst["rmse"], worst["flip"]))
+
+
+@pytest.mark.parametrize("cfg,extra", [("C5", {}), ("C1", dict(opticalVignettingDistance=3.0))])
+def test_batches_beyond_2_to_31_samples_are_split(gpu, cfg, extra):
+    """One call with 2^31 + 70 000 samples (103 GB of samples + records): the persistent kernels use 32-bit ray offsets, so
+    the launcher splits the batch; every ray must be accounted for once and the rays either side of the split must equal
+    the same rays computed as a small batch of their own (ray_index_base keys the streams)."""
+    import torch
+    n = (1 << 31) + 70_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * 48 + (8 << 30):
+        pytest.skip("needs 111 GB of free HBM")
+    c = CONFIGS[cfg]
+    cam = ZoicCamera(0)
+    cam.update(**dict(camera_params(cfg), **extra))
+    cam.set_precision(PRECISION_FAST)
+    samples = cam.generate_samples(n, c["width"], c["height"], c["spp"], seed=9)
+    out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device="cuda"))
+    cam.reset_counters()
+    cam.create_rays(samples, out=out)
+    torch.cuda.synchronize()
+    cnt = cam.counters()
+    assert cnt["succesRays"] + cnt["vignettedRays"] == n
+    lo, k = (1 << 31) - 50_000, 120_000                    # a window straddling the split
+    ref = cam.create_rays(samples[lo:lo + k].clone(), ray_index_base=lo)["rays"]
+    assert torch.equal(out["rays"][lo:lo + k].view(torch.int32), ref.view(torch.int32))
+    tail = out["rays"][n - 1000:]
+    assert bool(torch.isfinite(tail[:, 6]).all().item())   # the last rays were written
