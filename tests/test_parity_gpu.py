@@ -15,7 +15,7 @@ from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_count,
 pytestmark = pytest.mark.gpu
 
 DIR_RMSE_TOL = 1e-5        # BASELINE.json north_star: "ray-direction RMSE <1e-5 vs CPU reference"
-FLIP_TOL = 2e-3            # decision flips of fast mode; the reference's own FMA/no-FMA builds flip ~2e-5
+FLIP_TOL = float(os.environ.get("ZOIC_FLIP_TOL", "2e-3"))            # decision flips of fast mode; the reference's own FMA/no-FMA builds flip ~2e-5
 
 
 def bits(a):
