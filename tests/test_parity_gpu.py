@@ -565,7 +565,10 @@ def test_batches_beyond_2_to_31_samples_are_split(gpu, cfg, extra):
     the launcher splits the batch; every ray must be accounted for once and the rays either side of the split must equal
     the same rays computed as a small batch of their own (ray_index_base keys the streams)."""
     import torch
+    import gc
     n = (1 << 31) + 70_000
+    gc.collect()
+    torch.cuda.empty_cache()                 # earlier tests' buffers sit in torch's caching allocator
     free, _ = torch.cuda.mem_get_info()
     if free < n * 48 + (8 << 30):
         pytest.skip("needs 111 GB of free HBM")
