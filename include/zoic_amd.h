@@ -11,6 +11,16 @@
  *
  * All compute entry points run hand-written HIP kernels; there is no CPU fallback.  Every
  * function returns a zoic_status; ZOIC_OK == 0.
+ *
+ * Threading contract -- the reference's own (Arnold calls node_initialize / node_update / node_finish from one
+ * thread with no sample in flight, and camera_create_ray concurrently from every render thread, zoic.cpp:1752):
+ *   - zoic_camera_create / _update / _destroy / _set_* / _reset_counters: one thread at a time per camera, and no
+ *     ray call of that camera running on another thread.  (_update and _destroy wait for launches still queued.)
+ *   - zoic_create_rays_device / _host / _arnold, zoic_camera_create_ray, zoic_camera_reverse_ray,
+ *     zoic_camera_get_counters: any number of host threads on one camera at once.  Each call works on private
+ *     scratch and private HIP streams and waits only for its own work; results do not depend on the interleaving
+ *     (batched calls key every ray's retry stream by its global ray index, the per-sample call by its tid).
+ *   - No entry point changes the calling thread's current HIP device.
  */
 #ifndef ZOIC_AMD_H
 #define ZOIC_AMD_H
@@ -22,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ZOIC_AMD_ABI_VERSION 1
+#define ZOIC_AMD_ABI_VERSION 2
 
 typedef enum zoic_status {
     ZOIC_OK = 0,
@@ -134,16 +144,32 @@ zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed);
  * (zoic.cpp:648); a per-ray stream is the only order-independent restatement. */
 zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng_states,
                                     uint64_t ray_index_base, zoic_ray *d_rays, void *stream);
-/* same, host buffers: H2D, kernels, D2H, synchronous */
+/* same, host buffers: H2D, kernels, D2H in pieces on two private streams; returns when h_rays is complete */
 zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_samples, const uint32_t *h_rng_states,
                                   uint64_t ray_index_base, zoic_ray *h_rays);
 /* Arnold-layout batch: n AtCameraInput -> n AtCameraOutput (host).  outputs must arrive initialised the way
- * Arnold hands them to camera_create_ray (origin 0, weight 1; thin-lens reads output.origin, zoic.cpp:1777). */
+ * Arnold hands them to camera_create_ray (origin 0, weight 1; thin-lens reads output.origin, zoic.cpp:1777).
+ * Ray i draws its retries from the stream keyed by ray_index_base + i (see zoic_create_rays_device). */
 zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_camera_input *inputs,
                                     zoic_camera_output *outputs, uint64_t ray_index_base);
-/* camera_create_ray(node, input, output, tid): the per-sample signature (n == 1 of the above; latency bound) */
+/* camera_create_ray(node, input, output, tid), zoic.cpp:1752: the per-sample signature (latency bound: one launch
+ * per sample, sample and ray cross PCIe through mapped pinned memory).  Re-entrant: every tid owns a retry stream
+ * that carries over from call to call, so two samples that retry never see the same draws; tid 0's stream is the
+ * reference's process-global xor128 state (seeded 123456789..., advanced by node_update's LUT build and by every
+ * retry), so ONE render thread reproduces the reference's sequential output exactly (STRICT precision). */
 zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output,
                                    uint16_t tid);
+/* camera_reverse_ray, zoic.cpp:1992-1995: the reference returns false and writes nothing; so does this (returns 0). */
+int zoic_camera_reverse_ray(const zoic_camera *cam, const zoic_vec3 *Po, float fov, float *Ps /* [2] */,
+                            float *relative_time);
+
+/* Page-locked host memory for the buffers of zoic_create_rays_host: with pinned samples/rays the call runs as a
+ * two-stream pipeline (copy-in of piece k+1 under trace + copy-out of piece k) at PCIe rate.  zoic_host_register pins
+ * memory the caller already owns (keep it registered across calls: registration costs more than one transfer). */
+zoic_status zoic_host_alloc(size_t bytes, void **out);
+void        zoic_host_free(void *p);
+zoic_status zoic_host_register(void *p, size_t bytes);
+zoic_status zoic_host_unregister(void *p);
 
 /* synthetic sample generator used by bench/tests: pixel-jittered screen samples, uniform lens samples */
 zoic_status zoic_generate_samples_device(zoic_camera *cam, uint64_t n, uint64_t ray_index_base, uint32_t width,

@@ -1,0 +1,251 @@
+"""The C-ABI under the reference's calling contract: camera_create_ray is called concurrently from every
+render thread with a `tid` (zoic.cpp:1752); node_update is not.  Everything here goes through ctypes -> libzoic_amd.so;
+ctypes releases the GIL around the foreign call, so the Python threads below really do run the entry points in parallel.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from zoic_amd import PRECISION_STRICT, PinnedArray, ZoicCamera, ZoicError
+from zoic_amd import _capi
+from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_rng_states, synthetic_samples
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _c2_camera():
+    cam = ZoicCamera(0)
+    cam.update(**camera_params("C2"))
+    cam.set_precision(PRECISION_STRICT)
+    return cam
+
+
+def _slab(cfg, n, where):
+    c = CONFIGS[cfg]
+    base = int(c["width"] * int(c["height"] * where)) * c["spp"]
+    return synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1, ray_index_base=base), base
+
+
+def _out_tuple(o):
+    return (o.origin.x, o.origin.y, o.origin.z, o.dir.x, o.dir.y, o.dir.z, o.weight[0], o.dOdy.x, o.dDdy.z)
+
+
+def test_one_render_thread_replays_the_reference_process(gpu, oracle_lib):
+    """tid 0's retry stream is the reference's process-global xor128 state (advanced by node_update's LUT build, then by
+    every retry in sample order): per-sample calls from ONE thread must equal the oracle's sequential run, bit for bit,
+    including across a second node_update (zoic.cpp:647-652, 1411-1412, 1930)."""
+    cam = _c2_camera()
+    oc = oracle_lib.OracleCamera()
+    oc.update(**camera_params("C2"))
+    n = 1500
+    s, _ = _slab("C2", n, 0.03)            # near the frame's top edge: plenty of retries and zero-weight rays
+    ref = oc.create_rays(s)               # rng_states=None: the sequential global stream
+    assert (ref["flags"] & 1).mean() > 0.1
+    got = np.array([_out_tuple(cam.create_ray(*[float(v) for v in row], tid=0)) for row in s], np.float32)
+    assert np.array_equal(bits(got[:, 0:3].T.copy()), bits(ref["origin"]))
+    assert np.array_equal(bits(got[:, 3:6].T.copy()), bits(ref["dir"]))
+    assert np.array_equal(got[:, 6], ref["weight"])
+    # a lens change re-runs the LUT build from wherever the stream stands now -- in both implementations
+    p2 = dict(camera_params("C2"), fStop=4.0)
+    cam.update(**p2)
+    oc.update(**p2)
+    assert np.array_equal(cam.info()["lutBoxes"], oc.lut()[1])
+    ref2 = oc.create_rays(s[:300])
+    got2 = np.array([_out_tuple(cam.create_ray(*[float(v) for v in row], tid=0)) for row in s[:300]], np.float32)
+    assert np.array_equal(bits(got2[:, 3:6].T.copy()), bits(ref2["dir"]))
+
+
+def test_two_per_sample_calls_that_retry_draw_different_numbers(gpu):
+    """Round 1 keyed every per-sample call to ray index 0: all retried samples of a frame drew the same (u, v) sequence.
+    Now the tid's stream carries over, so the same sample submitted twice retries with different draws."""
+    cam = _c2_camera()
+    s, _ = _slab("C2", 4000, 0.03)
+    first = cam.create_rays(s)
+    k = int(np.argmax((first["tries"] > 0) & (first["weight"] != 0)))   # a sample that retries and then succeeds
+    row = [float(v) for v in s[k]]
+    a = _out_tuple(cam.create_ray(*row, tid=5))
+    b = _out_tuple(cam.create_ray(*row, tid=5))
+    c = _out_tuple(cam.create_ray(*row, tid=6))
+    assert a != b and a != c
+    assert a[7:] != (0.0, 0.0)             # retried => dOdy/dDdy written (zoic.cpp:1974-1977)
+    # same tid history on a fresh camera => same rays (deterministic per thread)
+    cam2 = _c2_camera()
+    assert _out_tuple(cam2.create_ray(*row, tid=5)) == a
+    assert _out_tuple(cam2.create_ray(*row, tid=5)) == b
+
+
+def test_sixteen_threads_of_mixed_calls_equal_the_serial_result(gpu):
+    """16 host threads x 1000 mixed camera_create_ray / batched Arnold-layout / host-buffer calls on ONE camera.
+    Each thread's results must equal what the same call sequence produces when the threads run one after another."""
+    n_threads, n_calls = 16, 1000
+    s_all, base = _slab("C2", 1 << 16, 0.04)
+
+    def work(cam, t, sink):
+        rng = np.random.default_rng(1000 + t)
+        out = []
+        for i in range(n_calls):
+            kind = rng.integers(0, 10)
+            if kind < 7:                                    # the per-sample callback with this thread's tid
+                row = s_all[rng.integers(0, len(s_all))]
+                out.append(np.array(_out_tuple(cam.create_ray(*[float(v) for v in row], tid=t)), np.float32))
+            elif kind < 9:                                  # a bucket of samples in AtCameraInput layout
+                m = int(rng.integers(1, 3000))
+                lo = int(rng.integers(0, len(s_all) - m))
+                inp = np.zeros((m, 7), np.float32)
+                inp[:, [0, 1, 4, 5]] = s_all[lo:lo + m]
+                out.append(cam.create_rays_arnold(inp, ray_index_base=base + lo).ravel())
+            else:                                           # host-buffer batch
+                m = int(rng.integers(1, 20000))
+                lo = int(rng.integers(0, len(s_all) - m))
+                r = cam.create_rays(s_all[lo:lo + m], ray_index_base=base + lo)
+                out.append(np.concatenate([r["planes"].ravel(), r["flags"].astype(np.float32)]))
+        sink[t] = np.concatenate(out)
+
+    serial, parallel = {}, {}
+    cam = _c2_camera()
+    for t in range(n_threads):
+        work(cam, t, serial)
+    done_serial = cam.counters()
+    cam.close()
+    cam = _c2_camera()
+    errors = []
+
+    def guarded(t):
+        try:
+            work(cam, t, parallel)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=guarded, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(n_threads):
+        assert np.array_equal(bits(serial[t]), bits(parallel[t])), "thread %d differs from its serial run" % t
+    assert cam.counters() == done_serial                   # the shared counters saw every ray exactly once
+    cam.close()
+
+
+def test_more_launches_in_flight_than_launch_slots(gpu):
+    """200 asynchronous launches on 8 streams with nothing waited for in between: more than the 64 launch slots, so slots
+    are reused behind their completion events.  Every batch must come out as when it runs alone."""
+    import torch
+    cam = ZoicCamera(0)
+    cam.update(**camera_params("C2"))
+    c = CONFIGS["C2"]
+    sizes = [50_000 + 7_919 * (i % 13) for i in range(200)]
+    bases = [c["width"] * 40 * c["spp"] + 100_003 * i for i in range(200)]
+    samples = [cam.generate_samples(n, c["width"], c["height"], c["spp"], seed=3, ray_index_base=b) for n, b in zip(sizes, bases)]
+    torch.cuda.synchronize()
+    alone = []
+    for s, b in zip(samples, bases):
+        alone.append(cam.create_rays(s, ray_index_base=b)["rays"].clone())
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    outs = [dict(rays=torch.empty((n, 8), dtype=torch.float32, device="cuda")) for n in sizes]
+    for i, (s, b) in enumerate(zip(samples, bases)):
+        cam.create_rays(s, ray_index_base=b, out=outs[i], stream=streams[i % 8].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(200):
+        assert torch.equal(outs[i]["rays"].view(torch.int32), alone[i].view(torch.int32)), "batch %d differs" % i
+
+
+def test_reverse_ray_is_false_like_the_reference(gpu):
+    cam = _c2_camera()
+    assert cam.reverse_ray((1.0, 2.0, 3.0), fov=0.5) is False      # zoic.cpp:1992-1995
+
+
+@pytest.mark.parametrize("n", [1, 777, 300_000, 5_000_000])
+def test_host_path_pieces_pinned_and_pageable_equal_the_device_path(gpu, n):
+    """zoic_create_rays_host cuts a call into pieces on two streams; pageable and page-locked caller buffers, with and
+    without caller-supplied stream states, must give the device path's rays."""
+    import torch
+    cam = ZoicCamera(0)
+    cam.set_bokeh_image(hexagon_bokeh())
+    cam.update(**camera_params("C3"))
+    c = CONFIGS["C3"]
+    base = c["width"] * 900 * c["spp"]
+    s = synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1, ray_index_base=base)
+    dev = cam.create_rays(torch.from_numpy(s).cuda(), ray_index_base=base)["rays"].cpu().numpy()
+    pageable = cam.create_rays(s, ray_index_base=base)
+    assert np.array_equal(pageable["rays"].view(np.uint32).reshape(n, 8), dev.view(np.uint32))
+    pin_s, pin_r = PinnedArray((n, 4), np.float32), PinnedArray((n,), _capi.RAY_DTYPE)
+    pin_s.array[:] = s
+    pinned = cam.create_rays(pin_s.array, ray_index_base=base, out=pin_r.array)
+    assert np.array_equal(pinned["rays"].view(np.uint32).reshape(n, 8), dev.view(np.uint32))
+    st = ray_rng_states(n, seed=9, ray_index_base=base)               # caller-supplied streams ride the same pieces
+    with_states = cam.create_rays(s, rng_states=st, ray_index_base=base)
+    dev_states = cam.create_rays(torch.from_numpy(s).cuda(), rng_states=torch.from_numpy(st.view(np.int32)).cuda(),
+                                 ray_index_base=base)["rays"].cpu().numpy()
+    assert np.array_equal(with_states["rays"].view(np.uint32).reshape(n, 8), dev_states.view(np.uint32))
+    pin_s.free(); pin_r.free()
+
+
+def test_failed_bokeh_load_is_not_forgotten(gpu):
+    """after a failed bokeh load a second update with the same parameters must not report success with the
+    image silently off; new pixels under an unchanged bokehPath must rebuild the CDFs."""
+    cam = ZoicCamera(0)
+    p = dict(camera_params("C3"))
+    with pytest.raises(ZoicError) as e:
+        cam.update(**p)                      # useImage with no pixels and a path that is not a .pfm file
+    assert e.value.status_name == "ZOIC_ERR_BOKEH_IMAGE"
+    with pytest.raises(ZoicError):
+        cam.update(**p)                      # round 1: returned ZOIC_OK here and sampled the disk instead
+    s, base = _slab("C3", 1000, 0.5)
+    with pytest.raises(ZoicError) as e:
+        cam.create_rays(s)
+    assert e.value.status_name == "ZOIC_ERR_NOT_UPDATED"
+    img = hexagon_bokeh()
+    cam.set_bokeh_image(img)
+    cam.update(**p)
+    a = cam.create_rays(s, ray_index_base=base)
+    cam.set_bokeh_image(np.ascontiguousarray(img[::-1, :, :] ** 2))   # same path, new pixels
+    cam.update(**p)
+    b = cam.create_rays(s, ray_index_base=base)
+    assert not np.array_equal(bits(a["planes"]), bits(b["planes"]))
+
+
+def test_non_monotone_cdf_keeps_the_reference_search(gpu, oracle_lib):
+    """negative luminance (HDR images) makes the CDFs non-monotone; counting entries <= u is then not
+    std::upper_bound.  Such tables must fall back to the reference's own binary search: strict stays bit-exact."""
+    rng = np.random.default_rng(5)
+    img = rng.random((40, 56, 3)).astype(np.float32)
+    img[rng.random((40, 56)) < 0.2] *= -0.5
+    p = dict(camera_params("C1"), useImage=True, bokehPath="mem:neg")
+    cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+    cam.set_bokeh_image(img); oc.set_bokeh_image(img)
+    cam.update(**p); oc.update(**p)
+    t = cam.bokeh_tables()
+    assert (np.diff(t["cdfRow"]) < 0).any() or (np.diff(t["cdfColumn"].reshape(40, 56), axis=1) < 0).any()
+    n = 1 << 15
+    s, base = _slab("C1", n, 0.5)
+    got = cam.create_rays(s, ray_index_base=base)
+    ref = oc.create_rays(s, rng_states=ray_rng_states(n, 1, base))
+    assert np.array_equal(got["flags"], ref["flags"])
+    assert np.array_equal(bits(got["planes"]), bits(ref["planes"]))
+
+
+def test_current_device_is_left_alone(gpu):
+    """Entry points run on the camera's device and restore the caller's current device."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    before = ctypes.c_int(-1)
+    hip.hipGetDevice(ctypes.byref(before))
+    cam = _c2_camera()
+    s, _ = _slab("C2", 100, 0.5)
+    cam.create_rays(s)
+    cam.counters()
+    after = ctypes.c_int(-1)
+    hip.hipGetDevice(ctypes.byref(after))
+    assert before.value == after.value
+    import torch
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(ValueError):
+            cam.create_rays(torch.zeros((4, 4), device="cuda:1"))

@@ -5,7 +5,7 @@ mirror of the reference's Arnold node interface over that C-ABI; it contains no 
 fallback -- if the library is missing, importing the camera raises.
 """
 from ._capi import PRECISION_FAST, PRECISION_STRICT, RAYTRACED, THINLENS, ZoicLibraryError  # noqa: F401
-from .camera import DEFAULTS, ZoicCamera, ZoicError, lens_path  # noqa: F401
+from .camera import DEFAULTS, PinnedArray, ZoicCamera, ZoicError, lens_path  # noqa: F401
 
-__all__ = ["ZoicCamera", "ZoicError", "ZoicLibraryError", "DEFAULTS", "lens_path", "RAYTRACED", "THINLENS",
+__all__ = ["ZoicCamera", "PinnedArray", "ZoicError", "ZoicLibraryError", "DEFAULTS", "lens_path", "RAYTRACED", "THINLENS",
            "PRECISION_STRICT", "PRECISION_FAST"]

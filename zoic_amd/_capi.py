@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ZOIC_AMD_LIB points at another build of the same library (A/B experiments, tools/); there is still no fallback
 LIB_PATH = os.environ.get("ZOIC_AMD_LIB") or os.path.join(HERE, "libzoic_amd.so")
 
+ABI_VERSION = 2
 MAX_LENS_SURFACES = 32
 LUT_ENTRIES = 32
 
@@ -83,6 +84,11 @@ SYMBOLS = {
     "zoic_create_rays_host": (C.c_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     "zoic_create_rays_arnold": (C.c_int, [_vp, _u64, C.POINTER(CameraInput), C.POINTER(CameraOutput), _u64]),
     "zoic_camera_create_ray": (C.c_int, [_vp, C.POINTER(CameraInput), C.POINTER(CameraOutput), C.c_uint16]),
+    "zoic_camera_reverse_ray": (C.c_int, [_vp, C.POINTER(Vec3), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "zoic_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "zoic_host_free": (None, [_vp]),
+    "zoic_host_register": (C.c_int, [_vp, C.c_size_t]),
+    "zoic_host_unregister": (C.c_int, [_vp]),
     "zoic_generate_samples_device": (C.c_int, [_vp, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _vp]),
     "zoic_camera_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "zoic_camera_reset_counters": (C.c_int, [_vp]),
@@ -120,7 +126,7 @@ def load(path=None):
             raise ZoicLibraryError("libzoic_amd.so lacks symbol %s declared in include/zoic_amd.h" % name)
         fn.restype = res
         fn.argtypes = args
-    if lib.zoic_abi_version() != 1:
+    if lib.zoic_abi_version() != ABI_VERSION:
         raise ZoicLibraryError("ABI version mismatch")
     if path is None:
         _lib = lib

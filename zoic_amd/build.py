@@ -31,23 +31,51 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libzoic_amd.so cannot be built (no CPU fallback exists)")
 
 
+OBJDIR = os.path.join(HERE, "build")
+
+
+def _deps():
+    return [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, s) for s in SOURCES] + _deps())
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
-        return LIB
+def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
+    """Compile every source to an object (in parallel, recompiling only what changed) and link the shared library."""
+    out = out or LIB
     extra_flags = list(extra_flags) + os.environ.get("ZOIC_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if out == LIB and not extra_flags and not force and not needs_build():
+        return LIB
+    objdir = objdir or (OBJDIR if not extra_flags else OBJDIR + "_" + "%08x" % (hash(" ".join(extra_flags)) & 0xffffffff))
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    cflags = [f for f in FLAGS if f != "-shared"] + extra_flags
+    newest_header = max(os.path.getmtime(d) for d in _deps())
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+        srcp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), newest_header):
+            continue
+        cmd = [hipcc] + cflags + ["-c", srcp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed on: %s" % ", ".join(failed))
+    link_extra = [f for f in extra_flags if f.startswith("-fsanitize") or f == "-g"]
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950"] + link_extra + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

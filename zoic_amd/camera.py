@@ -60,6 +60,35 @@ def rays_to_dict(rays):
                 tries=((flags >> 1) & 31).astype(np.int32))
 
 
+class PinnedArray:
+    """A numpy array over page-locked host memory (zoic_host_alloc): buffers of this kind let create_rays' host path
+    run as an asynchronous two-stream pipeline.  Keep the object alive as long as the array is used."""
+
+    def __init__(self, shape, dtype):
+        self._lib = _capi.load()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        st = self._lib.zoic_host_alloc(max(n, 1), C.byref(p))
+        if st != 0:
+            raise ZoicError(st, (self._lib.zoic_last_error_string() or b"").decode(errors="replace"))
+        self._p = p
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._lib.zoic_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class ZoicCamera:
     def __init__(self, device=0):
         self._lib = _capi.load()
@@ -150,7 +179,12 @@ class ZoicCamera:
         if s.ndim != 2 or s.shape[1] != 4:
             raise ValueError("samples must be (n, 4)")
         n = s.shape[0]
-        rays = np.empty(n, dtype=_capi.RAY_DTYPE)
+        if out is not None:   # caller-owned (e.g. pinned) record array
+            rays = out
+            if rays.dtype != np.dtype(_capi.RAY_DTYPE) or rays.shape != (n,) or not rays.flags.c_contiguous:
+                raise ValueError("out must be a contiguous (n,) array of zoic_ray records")
+        else:
+            rays = np.empty(n, dtype=_capi.RAY_DTYPE)
         rs_ptr = None
         if rng_states is not None:
             rs = np.ascontiguousarray(rng_states, dtype=np.uint32)
@@ -166,10 +200,14 @@ class ZoicCamera:
             raise ValueError("samples must be a contiguous (n,4) float32 tensor")
         if not samples.is_cuda:
             raise ValueError("torch samples must live on the GPU (use numpy for host buffers)")
+        if samples.device.index != self.device:
+            raise ValueError("samples live on cuda:%s but this camera is bound to device %d" % (samples.device.index, self.device))
         n = samples.shape[0]
         if out is None:
             out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device=samples.device))
         rays = out["rays"]
+        if rays.device != samples.device:
+            raise ValueError("out['rays'] must live on the samples' device")
         rs_ptr = None
         if rng_states is not None:
             if rng_states.dtype not in (torch.int32, torch.uint32) or tuple(rng_states.shape) != (n, 4):
@@ -194,6 +232,13 @@ class ZoicCamera:
         o.weight[0] = o.weight[1] = o.weight[2] = 1.0
         self._check(self._lib.zoic_camera_create_ray(self._h, C.byref(i), C.byref(o), int(tid)))
         return o
+
+    def reverse_ray(self, Po=(0.0, 0.0, 0.0), fov=0.0):
+        """camera_reverse_ray (zoic.cpp:1992-1995): always False, nothing written."""
+        po = _capi.Vec3(*[float(v) for v in Po])
+        ps = (C.c_float * 2)(0.0, 0.0)
+        t = C.c_float(0.0)
+        return bool(self._lib.zoic_camera_reverse_ray(self._h, C.byref(po), float(fov), ps, C.byref(t)))
 
     def create_rays_arnold(self, inputs, ray_index_base=0):
         """inputs: (n,7) float32 AtCameraInput rows -> (n,21) float32 AtCameraOutput rows (weight initialised to 1)."""

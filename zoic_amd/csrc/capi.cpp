@@ -5,13 +5,25 @@
 //   zoic_camera_update   <- node_update      zoic.cpp:1575-1720
 //   zoic_create_rays_*   <- camera_create_ray zoic.cpp:1752-1990
 //   zoic_camera_destroy  <- node_finish      zoic.cpp:1723-1749
+//
+// Threading (the reference's contract): node_initialize / node_update / node_finish run on one thread with no
+// ray call in flight; camera_create_ray is called concurrently from every render thread.  Accordingly every
+// zoic_create_rays_* / zoic_camera_create_ray entry point may be called from any number of host threads on ONE camera:
+//   * a kernel launch takes a LaunchSlot (its own set of work cursors, guarded by an event: a slot is handed to the next
+//     launch only behind the previous user's completion, device side, without blocking the host);
+//   * the host-buffer entry points lease a CallContext (two private HIP streams, private device + pinned scratch) for the
+//     duration of the call, synchronise only their own streams, and never touch camera-wide scratch;
+//   * the per-sample adapter keeps one retry stream per Arnold thread id (tid 0 = the reference's own global xor128 state).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,9 +39,9 @@ namespace {
 
 thread_local std::string g_lastError;
 
-constexpr unsigned kWorkCursors = 64;   // launches of one camera that may be in flight at once
+constexpr unsigned kLaunchSlots = 64;   // launches of one camera that may be in flight at once without waiting on each other
 constexpr unsigned kCursorStride = kCursorParts * kCursorPartStride;  // one launch's set of partition cursors (kernels.hpp)
-// a >2^31-sample call splits into several launches, each taking the next slot of the ring (kernels.hip)
+// (a >2^31-sample call splits into several launches that reuse ONE slot: they are ordered on the caller's stream)
 
 zoic_status fail(zoic_status s, const std::string &msg)
 {
@@ -66,6 +78,89 @@ struct DeviceBuffer {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+// page-locked host memory, mapped into the device's address space (zero-copy for the per-sample adapter, async D2H target
+// for the Arnold-layout batch path)
+struct PinnedBuffer {
+    void *host = nullptr, *dev = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        hipError_t e = hipHostMalloc(&host, bytes, hipHostMallocMapped);
+        if (e != hipSuccess) { host = nullptr; return e; }
+        e = hipHostGetDevicePointer(&dev, host, 0);
+        if (e != hipSuccess) { (void)hipHostFree(host); host = dev = nullptr; return e; }
+        cap = bytes;
+        return hipSuccess;
+    }
+    void release() { if (host) (void)hipHostFree(host); host = dev = nullptr; cap = 0; }
+};
+
+// every entry point runs on the camera's device and leaves the calling thread's current device as it found it
+class DeviceGuard {
+    int prev_ = -1;
+    bool switched_ = false;
+    hipError_t err_ = hipSuccess;
+public:
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        if (prev_ != device) { err_ = hipSetDevice(device); switched_ = err_ == hipSuccess && prev_ >= 0; }
+    }
+    ~DeviceGuard() { if (switched_) (void)hipSetDevice(prev_); }
+    hipError_t error() const { return err_; }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// One launch's work cursors.  `done` is recorded behind the launch that used the slot last; the next launch to draw the
+// slot makes its stream wait on it (hipStreamWaitEvent), so cursors are never reset under a running kernel however many
+// launches are in flight -- with up to kLaunchSlots of them no launch waits at all.
+struct LaunchSlot {
+    std::mutex m;                 // held only while a launch is being enqueued
+    unsigned int *cursor = nullptr;
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+};
+
+// Private scratch of ONE host-buffer call in flight: leased from the camera's pool for the duration of the call.
+// Two streams / two buffer sets: piece k+1 is copied in while piece k is traced and copied out.
+struct CallContext {
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t landed[2] = {nullptr, nullptr};   // D2H of a piece has landed in hRays[b]
+    DeviceBuffer<float> dSamples[2], dInputs7[2];
+    DeviceBuffer<RayRecord> dRays[2];
+    DeviceBuffer<uint32_t> dRng[2];
+    PinnedBuffer hRays[2];                       // Arnold-layout path: records land here, the host expands them to 84 bytes
+    PinnedBuffer one;                            // per-sample adapter: {sample 16 B, rng state 16 B, ray record 32 B}, zero-copy
+    hipError_t init()
+    {
+        for (int b = 0; b < 2; ++b) {
+            hipError_t e = hipStreamCreateWithFlags(&stream[b], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&landed[b], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        return one.reserve(64);
+    }
+    void release()
+    {
+        for (int b = 0; b < 2; ++b) {
+            if (stream[b]) { (void)hipStreamSynchronize(stream[b]); (void)hipStreamDestroy(stream[b]); stream[b] = nullptr; }
+            if (landed[b]) { (void)hipEventDestroy(landed[b]); landed[b] = nullptr; }
+            dSamples[b].release(); dInputs7[b].release(); dRays[b].release(); dRng[b].release(); hRays[b].release();
+        }
+        one.release();
+    }
+};
+
+// camera_create_ray's `tid` (zoic.cpp:1752): one retry stream per render thread, advanced by every call that retries.
+struct TidState {
+    std::mutex m;   // Arnold never runs two samples of one tid at once; a caller that does is serialised, not corrupted
+    Rng rng{};
+};
+constexpr unsigned kTidStates = 65536;   // uint16_t tid
+
 }  // namespace
 
 struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
@@ -79,9 +174,10 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     uint32_t seed = 1;
     bool updated = false;
     bool lutOnHost = false;
-    // pending inputs
+    // pending inputs; the dirty flags force the rebuild on the next update even under an unchanged path
     std::vector<float> pendingPixels; int pendW = 0, pendH = 0, pendC = 0;
     std::string lensText; bool haveLensText = false;
+    bool bokehDirty = false, lensDirty = false;
     // flattened tables
     KolbTable kolb{};
     ThinTable thin{};
@@ -91,14 +187,62 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     DeviceBuffer<int32_t> dRowIdx, dColIdx;
     BokehTables bokehDev{};
     DeviceCounters *dCounters = nullptr;
-    DeviceBuffer<float> dSamples, dInputs7, dProbeU, dProbeV;
-    DeviceBuffer<RayRecord> dRays;
-    DeviceBuffer<uint32_t> dRng;
+    DeviceBuffer<float> dProbeU, dProbeV;   // node_update scratch (single-threaded by contract)
     DeviceBuffer<uint8_t> dProbeOk;
     unsigned int *dProbeTir = nullptr;
-    unsigned int *dWorkCursor = nullptr;   // ring of kWorkCursors chunk cursors: launches in flight on different streams never share one
-    unsigned int nextCursor = 0;
+    // ---- concurrent ray calls (see the threading note at the top of this file)
+    unsigned int *dWorkCursor = nullptr;    // kLaunchSlots sets of partition cursors
+    LaunchSlot slots[kLaunchSlots];
+    std::atomic<unsigned> nextSlot{0};
+    std::mutex poolM;
+    std::vector<CallContext *> freeContexts;
+    std::vector<std::unique_ptr<CallContext>> contexts;
+    std::unique_ptr<std::atomic<TidState *>[]> tidStates;   // kTidStates entries, created on first use
+    std::mutex tidCreateM;
+
+    TidState *tid_state(uint16_t tid);
+    CallContext *lease_context(hipError_t &err);
+    void return_context(CallContext *c);
 };
+
+TidState *zoic_camera::tid_state(uint16_t tid)
+{
+    std::atomic<TidState *> &slot = tidStates[tid];
+    TidState *t = slot.load(std::memory_order_acquire);
+    if (t) return t;
+    std::lock_guard<std::mutex> lk(tidCreateM);
+    t = slot.load(std::memory_order_relaxed);
+    if (!t) {
+        t = new TidState();
+        // tid 0 is never seeded here: it IS the camera's `stream` (the reference's global xor128 state), so a single
+        // render thread reproduces the reference's sequential output; the other threads get streams of their own
+        t->rng = rng_for_ray(seed, (0xA7100000ull | tid) << 32);
+        slot.store(t, std::memory_order_release);
+    }
+    return t;
+}
+
+CallContext *zoic_camera::lease_context(hipError_t &err)
+{
+    err = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(poolM);
+        if (!freeContexts.empty()) { CallContext *c = freeContexts.back(); freeContexts.pop_back(); return c; }
+    }
+    std::unique_ptr<CallContext> fresh(new CallContext());   // as many contexts as calls were ever in flight at once
+    err = fresh->init();
+    if (err != hipSuccess) { fresh->release(); return nullptr; }
+    CallContext *c = fresh.get();
+    std::lock_guard<std::mutex> lk(poolM);
+    contexts.push_back(std::move(fresh));
+    return c;
+}
+
+void zoic_camera::return_context(CallContext *c)
+{
+    std::lock_guard<std::mutex> lk(poolM);
+    freeContexts.push_back(c);
+}
 
 namespace {
 
@@ -207,6 +351,16 @@ zoic_status upload_bokeh(zoic_camera *cam)
     ZOIC_HIP(hipMemcpy(cam->dColIdx.ptr, im.columnIndices.data(), xy * sizeof(int32_t), hipMemcpyHostToDevice));
     BokehTables &B = cam->bokehDev;
     B.cdfRow = cam->dCdfRow.ptr; B.rowIndices = cam->dRowIdx.ptr; B.cdfColumn = cam->dCdfColumn.ptr; B.columnIndices = cam->dColIdx.ptr;
+    // The pyramid search (count of entries <= u) and the cell records equal std::upper_bound only on non-decreasing,
+    // NaN-free CDFs.  Negative or NaN luminance (HDR images) can break that: such tables keep the reference's own binary
+    // search (levels == 0, no cell records), which visits the same elements as std::upper_bound on any input.
+    const auto monotone = [](const float *a, int n) {
+        for (int i = 0; i < n; ++i) if (!(a[i] == a[i]) || (i > 0 && a[i] < a[i - 1])) return false;
+        return true;
+    };
+    bool sorted = monotone(im.cdfRow.data(), im.y);
+    for (size_t r = 0; sorted && r < y; ++r) sorted = monotone(im.cdfColumn.data() + r * im.x, im.x);
+    if (!sorted) return ZOIC_OK;
     // search pyramids (device layout only; same numbers as the reference tables)
     const Pyramid rp = pyramid_shape(im.y), cp = pyramid_shape(im.x);
     if (rp.levels == 0 || cp.levels == 0) return ZOIC_OK;
@@ -235,16 +389,9 @@ zoic_status upload_bokeh(zoic_camera *cam)
         B.colCount[j] = cshape.count[j];
     }
     B.levels = levels;
-    // cell records (tables.hpp): rows <= 2048 (the row records live in LDS: 32 KB at most), columns <= 4096, both CDFs
-    // non-decreasing and NaN-free (anything else keeps the pyramid / reference search)
+    // cell records (tables.hpp): rows <= 2048 (the row records live in LDS: 32 KB at most), columns <= 4096
     if (im.x <= 4096 && im.y <= 2048) {
-        const auto monotone = [](const float *a, int n) {
-            for (int i = 0; i < n; ++i) if (!(a[i] == a[i]) || (i > 0 && a[i] < a[i - 1])) return false;
-            return true;
-        };
-        bool ok = monotone(im.cdfRow.data(), im.y);
-        for (size_t r = 0; ok && r < y; ++r) ok = monotone(im.cdfColumn.data() + r * im.x, im.x);
-        if (ok) {
+        {
             const auto cellCount = [](int n) { int g = 16; while (g < n) g <<= 1; return g; };
             const int gRow = cellCount(im.y), gCol = cellCount(im.x);
             const size_t nCells = static_cast<size_t>(gRow) + y * static_cast<size_t>(gCol);
@@ -304,6 +451,75 @@ void exposure_terms(float exposureControl, float &mul, int32_t &on)  // zoic.cpp
     on = 0; mul = 1.0f;
     if (exposureControl > 0.0f) { on = 1; mul = 1.0f + e2; }
     else if (exposureControl < 0.0f) { on = 1; mul = 1.0f / (1.0f + e2); }
+}
+
+class ContextLease {   // a CallContext for the duration of one host-buffer call
+    zoic_camera *cam_;
+    CallContext *ctx_;
+    hipError_t err_ = hipSuccess;
+public:
+    explicit ContextLease(zoic_camera *cam) : cam_(cam), ctx_(cam->lease_context(err_)) {}
+    ~ContextLease() { if (ctx_) cam_->return_context(ctx_); }
+    explicit operator bool() const { return ctx_ != nullptr; }
+    hipError_t error() const { return err_; }
+    CallContext &operator*() const { return *ctx_; }
+    ContextLease(const ContextLease &) = delete;
+    ContextLease &operator=(const ContextLease &) = delete;
+};
+
+zoic_status check_ray_call(const zoic_camera *cam)
+{
+    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
+    if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera: rays need a gfx950 device (no CPU path)");
+    if (!cam->updated) return fail(ZOIC_ERR_NOT_UPDATED, "zoic_camera_update has not succeeded yet");
+    return ZOIC_OK;
+}
+
+// One launch of camera_create_ray over n samples on `stream`, asynchronous.  Safe to call from many host threads at once.
+zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng, uint64_t rayBase, RayRecord *d_rays,
+                        hipStream_t stream)
+{
+    static_assert(sizeof(zoic_ray) == sizeof(RayRecord), "zoic_ray layout");
+    const int model = cam->params.p.lensModel;
+    if (model != ZOIC_RAYTRACED && model != ZOIC_THINLENS)
+        return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
+    LaunchSlot &slot = cam->slots[cam->nextSlot.fetch_add(1u, std::memory_order_relaxed) % kLaunchSlots];
+    std::lock_guard<std::mutex> lk(slot.m);
+    // the slot's previous user (another stream, maybe another thread) must be done before its cursors are reset
+    if (slot.recorded) ZOIC_HIP(hipStreamWaitEvent(stream, slot.done, 0));
+    const bool fast = cam->precision == ZOIC_PRECISION_FAST;
+    int rc;
+    if (model == ZOIC_RAYTRACED)
+        rc = launch_kolb_rays(cam->kolb, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot.cursor, fast, stream);
+    else
+        rc = launch_thin_rays(cam->thin, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot.cursor, fast, stream);
+    if (rc != 0) return fail(ZOIC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+    ZOIC_HIP(hipEventRecord(slot.done, stream));
+    slot.recorded = true;
+    return ZOIC_OK;
+}
+
+// samples per piece of the host-buffer pipeline: about eight pieces per call, 256 Ki ... 4 Mi samples each
+// (a piece must amortise a launch's fixed cost and still leave something to overlap); ZOIC_HOST_PIECE overrides
+uint64_t host_piece(uint64_t n)
+{
+    static const uint64_t forced = [] { const char *e = std::getenv("ZOIC_HOST_PIECE"); return e ? static_cast<uint64_t>(std::atoll(e)) : 0ull; }();
+    if (forced) return forced;
+    uint64_t p = ((n + 7) / 8 + 65535) / 65536 * 65536;
+    if (p < (256ull << 10)) p = 256ull << 10;
+    if (p > (4ull << 20)) p = 4ull << 20;
+    return p;
+}
+
+// one 32-byte record -> the AtCameraOutput fields zoic writes (zoic.cpp:1960-1961, 1974-1977, 1952, 1981-1987)
+inline void expand_record(const zoic_ray &r, zoic_camera_output &o)
+{
+    o.origin = zoic_vec3{r.ox, r.oy, r.oz};
+    o.dir = zoic_vec3{r.dx, r.dy, r.dz};
+    const float w = r.weight;
+    if (w == 0.0f) o.weight[0] = o.weight[1] = o.weight[2] = 0.0f;  // output.weight = 0.0f, zoic.cpp:1825/1952
+    else if (w != 1.0f) { o.weight[0] *= w; o.weight[1] *= w; o.weight[2] *= w; }  // exposure factor
+    if (r.flags & 1u) { o.dOdy = o.origin; o.dDdy = o.dir; }  // zoic.cpp:1974-1977
 }
 
 }  // namespace
@@ -366,20 +582,27 @@ zoic_status zoic_camera_create(int device, zoic_camera **out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(ZOIC_ERR_NO_DEVICE, "no HIP device visible: libzoic_amd has no CPU path");
     if (device < 0 || device >= n) return fail(ZOIC_ERR_INVALID_ARGUMENT, "device index out of range");
-    ZOIC_HIP(hipSetDevice(device));
-    zoic_camera *cam = new zoic_camera();
+    DeviceGuard guard(device);
+    ZOIC_HIP(guard.error());
+    std::unique_ptr<zoic_camera> cam(new zoic_camera());
     cam->device = device;
     rng_seed_reference(cam->stream);
     const char *env = std::getenv("ZOIC_LUT_HOST");
     cam->lutOnHost = env && env[0] == '1';
+    cam->tidStates.reset(new std::atomic<TidState *>[kTidStates]);
+    for (unsigned i = 0; i < kTidStates; ++i) cam->tidStates[i].store(nullptr, std::memory_order_relaxed);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&cam->dCounters), sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipMemset(cam->dCounters, 0, sizeof(DeviceCounters));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), kWorkCursors * kCursorStride * sizeof(unsigned int));
-    if (e != hipSuccess) {
-        delete cam;
-        return fail(ZOIC_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), kLaunchSlots * kCursorStride * sizeof(unsigned int));
+    for (unsigned i = 0; e == hipSuccess && i < kLaunchSlots; ++i) {
+        cam->slots[i].cursor = cam->dWorkCursor + i * kCursorStride;
+        e = hipEventCreateWithFlags(&cam->slots[i].done, hipEventDisableTiming);
     }
-    *out = cam;
+    if (e != hipSuccess) {
+        zoic_camera_destroy(cam.release());
+        return fail(ZOIC_ERR_HIP, std::string("camera allocation: ") + hipGetErrorString(e));
+    }
+    *out = cam.release();
     return ZOIC_OK;
 }
 
@@ -387,13 +610,19 @@ void zoic_camera_destroy(zoic_camera *cam)
 {
     if (!cam) return;
     if (cam->device == ZOIC_DEVICE_NONE) { delete cam; return; }
-    (void)hipSetDevice(cam->device);
-    cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release(); cam->dBokehCells.release();
-    cam->dSamples.release(); cam->dRays.release(); cam->dInputs7.release(); cam->dRng.release();
-    cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release();
-    if (cam->dProbeTir) (void)hipFree(cam->dProbeTir);
-    if (cam->dCounters) (void)hipFree(cam->dCounters);
-    if (cam->dWorkCursor) (void)hipFree(cam->dWorkCursor);
+    {
+        DeviceGuard guard(cam->device);
+        (void)hipDeviceSynchronize();   // launches the caller left in flight still read the tables and cursors freed below
+        for (auto &c : cam->contexts) c->release();
+        cam->contexts.clear(); cam->freeContexts.clear();
+        for (unsigned i = 0; i < kLaunchSlots; ++i) if (cam->slots[i].done) (void)hipEventDestroy(cam->slots[i].done);
+        cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release(); cam->dBokehCells.release();
+        cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release();
+        if (cam->dProbeTir) (void)hipFree(cam->dProbeTir);
+        if (cam->dCounters) (void)hipFree(cam->dCounters);
+        if (cam->dWorkCursor) (void)hipFree(cam->dWorkCursor);
+    }
+    if (cam->tidStates) for (unsigned i = 0; i < kTidStates; ++i) delete cam->tidStates[i].load(std::memory_order_relaxed);
     delete cam;
 }
 
@@ -406,6 +635,7 @@ zoic_status zoic_camera_set_bokeh_image(zoic_camera *cam, int width, int height,
         cam->pendingPixels.assign(pixels, pixels + static_cast<size_t>(width) * height * nchannels);
         cam->pendW = width; cam->pendH = height; cam->pendC = nchannels;
     }
+    cam->bokehDirty = true;   // new pixels under an unchanged bokehPath still rebuild the CDFs
     return ZOIC_OK;
 }
 
@@ -414,6 +644,7 @@ zoic_status zoic_camera_set_lens_text(zoic_camera *cam, const char *text, size_t
     if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
     cam->haveLensText = text != nullptr;
     cam->lensText.assign(text ? text : "", text ? len : 0);
+    cam->lensDirty = true;    // new text under an unchanged lensDataPath still rebuilds the lens
     return ZOIC_OK;
 }
 
@@ -430,6 +661,15 @@ zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed)
     cam->seed = seed;
     cam->kolb.seed = seed;
     cam->thin.seed = seed;
+    // the per-thread retry streams of the per-sample adapter restart from the new seed (tid 0 keeps the reference's state)
+    if (cam->tidStates) {
+        std::lock_guard<std::mutex> lk(cam->tidCreateM);
+        for (unsigned i = 1; i < kTidStates; ++i)
+            if (TidState *t = cam->tidStates[i].load(std::memory_order_acquire)) {
+                std::lock_guard<std::mutex> tl(t->m);
+                t->rng = rng_for_ray(seed, (0xA7100000ull | i) << 32);
+            }
+    }
     return ZOIC_OK;
 }
 
@@ -437,13 +677,27 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
 {
     if (!cam || !p) return fail(ZOIC_ERR_INVALID_ARGUMENT, "NULL argument");
     const bool onDevice = cam->device != ZOIC_DEVICE_NONE;
-    if (onDevice) ZOIC_HIP(hipSetDevice(cam->device));
-    zoic_status status = ZOIC_OK;
+    std::unique_ptr<DeviceGuard> guard;
+    if (onDevice) {
+        guard.reset(new DeviceGuard(cam->device));
+        ZOIC_HIP(guard->error());
+        // node_update never runs beside camera_create_ray (Arnold's contract), but launches the caller queued earlier
+        // may still be reading the tables rebuilt below
+        ZOIC_HIP(hipDeviceSynchronize());
+    }
     const std::string bokehPath = p->bokehPath ? p->bokehPath : "", lensPath = p->lensDataPath ? p->lensDataPath : "";
+    // Whatever fails below, the camera is left "not updated" with no remembered parameters, so the next update rebuilds
+    // everything instead of trusting a half-applied state.
+    const bool hadParams = cam->params.valid;
+    OwnedParams previous;
+    if (hadParams) previous = cam->params;
+    cam->params.valid = false;
+    cam->updated = false;
 
     // bokeh image -> CDF tables, zoic.cpp:1587-1593
-    if (params_bokeh_changed(*p, cam->params)) {
+    if (params_bokeh_changed(*p, previous) || (p->useImage && cam->bokehDirty)) {
         cam->image.clear();
+        cam->bokehDev = BokehTables{};
         if (p->useImage) {
             bool ok = false;
             std::vector<float> filePx;
@@ -458,9 +712,10 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
                 if (rc > 0) return fail(ZOIC_ERR_HIP, std::string("bokeh CDF kernels: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
                 ok = rc == 0 ? cam->image.valid() : cam->image.build(px, w, h, c);
             }
-            if (!ok) status = fail(ZOIC_ERR_BOKEH_IMAGE, "[ZOIC] Couldn't open bokeh image!");
-            else if (onDevice) { if (zoic_status s = upload_bokeh(cam)) return s; }
+            if (!ok) { cam->image.clear(); return fail(ZOIC_ERR_BOKEH_IMAGE, "[ZOIC] Couldn't open bokeh image!"); }
+            if (onDevice) { if (zoic_status s = upload_bokeh(cam)) { cam->image.clear(); return s; } }
         }
+        cam->bokehDirty = false;
     }
     const bool imageOn = p->useImage && cam->image.valid();
 
@@ -471,7 +726,7 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
         cam->apertureRadius = p->focalLength / (2.0f * p->fStop);
         break;
     case ZOIC_RAYTRACED:  // zoic.cpp:1612-1711
-        if (params_lens_changed(*p, cam->params)) {
+        if (params_lens_changed(*p, previous) || cam->lensDirty) {
             std::string text;
             if (cam->haveLensText) text = cam->lensText;
             else {
@@ -482,7 +737,7 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
                 while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
                 std::fclose(f);
             }
-            cam->updated = false;
+            cam->lensDirty = true;   // until the rebuild below has gone through
             if (zoic_status s = lens_error_status(cam->lens.parse(text.data(), text.size()))) return s;
             g_lastError.clear();
             LensError le = cam->lens.prepare(p->focalLength, p->fStop, p->focalDistance, p->kolbSamplingLUT != 0, cam->stream,
@@ -492,6 +747,7 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
             // counters restart with the lens (zoic.cpp:1626-1628); the precompute's TIR bumps stay in (zoic.cpp:1135 ff.)
             DeviceCounters zero{0, 0, cam->lens.precomputeTIR};
             if (onDevice) ZOIC_HIP(hipMemcpy(cam->dCounters, &zero, sizeof(zero), hipMemcpyHostToDevice));
+            cam->lensDirty = false;
         }
         break;
     default: break;
@@ -521,107 +777,190 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
         exposure_terms(p->exposureControl, t.exposureMul, t.exposureOn);
         t.seed = cam->seed;
     }
-    cam->updated = (status == ZOIC_OK);
-    return status;
+    cam->updated = true;
+    return ZOIC_OK;
 }
 
 zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng_states,
                                     uint64_t ray_index_base, zoic_ray *d_rays, void *stream)
 {
-    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
-    if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera: rays need a gfx950 device (no CPU path)");
-    if (!cam->updated) return fail(ZOIC_ERR_NOT_UPDATED, "zoic_camera_update has not succeeded yet");
+    if (zoic_status s = check_ray_call(cam)) return s;
     if (n == 0) return ZOIC_OK;
     if (!d_samples) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_samples is NULL");
     if (reinterpret_cast<uintptr_t>(d_samples) & 15u) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_samples must be 16-byte aligned");
     if (d_rng_states && (reinterpret_cast<uintptr_t>(d_rng_states) & 15u)) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_rng_states must be 16-byte aligned");
     if (!d_rays || (reinterpret_cast<uintptr_t>(d_rays) & 15u)) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_rays must be non-NULL and 16-byte aligned");
-    static_assert(sizeof(zoic_ray) == sizeof(RayRecord), "zoic_ray layout");
-    ZOIC_HIP(hipSetDevice(cam->device));
-    RayRecord *planes = reinterpret_cast<RayRecord *>(d_rays);
-    int rc = 0;
-    switch (cam->params.p.lensModel) {
-    case ZOIC_RAYTRACED:
-        rc = launch_kolb_rays(cam->kolb, bokeh_tables(cam), d_samples, d_rng_states, ray_index_base, n, planes, cam->dCounters,
-                              cam->dWorkCursor + (cam->nextCursor++ % kWorkCursors) * kCursorStride,
-                              cam->precision == ZOIC_PRECISION_FAST, stream);
-        break;
-    case ZOIC_THINLENS:
-        rc = launch_thin_rays(cam->thin, bokeh_tables(cam), d_samples, d_rng_states, ray_index_base, n, planes, cam->dCounters,
-                              cam->dWorkCursor + (cam->nextCursor++ % kWorkCursors) * kCursorStride,
-                              cam->precision == ZOIC_PRECISION_FAST, stream);
-        break;
-    default:
-        return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
-    }
-    if (rc != 0) return fail(ZOIC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-    return ZOIC_OK;
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    return launch_rays(cam, n, d_samples, d_rng_states, ray_index_base, reinterpret_cast<RayRecord *>(d_rays), static_cast<hipStream_t>(stream));
 }
 
 zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_samples, const uint32_t *h_rng_states,
                                   uint64_t ray_index_base, zoic_ray *h_rays)
 {
-    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
-    if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera: rays need a gfx950 device (no CPU path)");
-    if (!cam->updated) return fail(ZOIC_ERR_NOT_UPDATED, "zoic_camera_update has not succeeded yet");
+    if (zoic_status s = check_ray_call(cam)) return s;
     if (n == 0) return ZOIC_OK;
     if (!h_samples) return fail(ZOIC_ERR_INVALID_ARGUMENT, "h_samples is NULL");
-    ZOIC_HIP(hipSetDevice(cam->device));
     if (!h_rays) return fail(ZOIC_ERR_INVALID_ARGUMENT, "h_rays is NULL");
-    ZOIC_HIP(cam->dSamples.reserve(n * 4));
-    ZOIC_HIP(cam->dRays.reserve(n));
-    ZOIC_HIP(hipMemcpy(cam->dSamples.ptr, h_samples, n * 16, hipMemcpyHostToDevice));
-    const uint32_t *dRng = nullptr;
-    if (h_rng_states) {
-        ZOIC_HIP(cam->dRng.reserve(n * 4));
-        ZOIC_HIP(hipMemcpy(cam->dRng.ptr, h_rng_states, n * 16, hipMemcpyHostToDevice));
-        dRng = cam->dRng.ptr;
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    ContextLease lease(cam);
+    if (!lease) return fail(ZOIC_ERR_HIP, std::string("call context: ") + hipGetErrorString(lease.error()));
+    CallContext &C = *lease;
+    // Pieces alternate between the context's two streams: while piece k is traced and copied out, piece k+1 is copied in
+    // (PCIe is full duplex).  Operations on one stream are ordered, so the per-stream device buffers need no host-side
+    // bookkeeping.  With page-locked caller buffers (zoic_host_alloc / zoic_host_register) every copy is truly
+    // asynchronous; with pageable ones hipMemcpyAsync stages internally and the pipeline degrades gracefully.
+    const uint64_t piece = host_piece(n);
+    const size_t cap = static_cast<size_t>(std::min<uint64_t>(n, piece));
+    for (int b = 0; b < 2 && (b == 0 || n > piece); ++b) {
+        ZOIC_HIP(C.dSamples[b].reserve(cap * 4));
+        ZOIC_HIP(C.dRays[b].reserve(cap));
+        if (h_rng_states) ZOIC_HIP(C.dRng[b].reserve(cap * 4));
     }
-    if (zoic_status s = zoic_create_rays_device(cam, n, cam->dSamples.ptr, dRng, ray_index_base,
-                                                reinterpret_cast<zoic_ray *>(cam->dRays.ptr), nullptr)) return s;
-    ZOIC_HIP(hipDeviceSynchronize());
-    ZOIC_HIP(hipMemcpy(h_rays, cam->dRays.ptr, n * sizeof(zoic_ray), hipMemcpyDeviceToHost));
-    return ZOIC_OK;
+    zoic_status status = ZOIC_OK;
+    uint64_t k = 0;
+    for (uint64_t off = 0; off < n && status == ZOIC_OK; off += piece, ++k) {
+        const int b = static_cast<int>(k & 1u);
+        const uint64_t m = std::min<uint64_t>(piece, n - off);
+        hipStream_t st = C.stream[b];
+        hipError_t e = hipMemcpyAsync(C.dSamples[b].ptr, h_samples + off * 4, m * 16, hipMemcpyHostToDevice, st);
+        const uint32_t *dRng = nullptr;
+        if (e == hipSuccess && h_rng_states) {
+            e = hipMemcpyAsync(C.dRng[b].ptr, h_rng_states + off * 4, m * 16, hipMemcpyHostToDevice, st);
+            dRng = C.dRng[b].ptr;
+        }
+        if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e)); break; }
+        status = launch_rays(cam, m, C.dSamples[b].ptr, dRng, ray_index_base + off, C.dRays[b].ptr, st);
+        if (status != ZOIC_OK) break;
+        e = hipMemcpyAsync(h_rays + off, C.dRays[b].ptr, m * sizeof(zoic_ray), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+    }
+    for (int b = 0; b < 2; ++b) {   // own streams only: other threads' calls are not waited for
+        const hipError_t e = hipStreamSynchronize(C.stream[b]);
+        if (e != hipSuccess && status == ZOIC_OK) status = fail(ZOIC_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(e));
+    }
+    return status;
 }
 
 zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,
                                     uint64_t ray_index_base)
 {
-    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
-    if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera: rays need a gfx950 device (no CPU path)");
-    if (!cam->updated) return fail(ZOIC_ERR_NOT_UPDATED, "zoic_camera_update has not succeeded yet");
+    if (zoic_status s = check_ray_call(cam)) return s;
     if (n == 0) return ZOIC_OK;
     if (!inputs || !outputs) return fail(ZOIC_ERR_INVALID_ARGUMENT, "NULL argument");
     static_assert(sizeof(zoic_camera_input) == 28 && sizeof(zoic_camera_output) == 84, "Arnold POD layout");
-    ZOIC_HIP(hipSetDevice(cam->device));
-    ZOIC_HIP(cam->dInputs7.reserve(n * 7));
-    ZOIC_HIP(cam->dSamples.reserve(n * 4));
-    ZOIC_HIP(cam->dRays.reserve(n));
-    ZOIC_HIP(hipMemcpy(cam->dInputs7.ptr, inputs, n * sizeof(zoic_camera_input), hipMemcpyHostToDevice));
-    if (int rc = launch_pack_inputs(cam->dInputs7.ptr, cam->dSamples.ptr, n, nullptr))
-        return fail(ZOIC_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-    if (zoic_status s = zoic_create_rays_device(cam, n, cam->dSamples.ptr, nullptr, ray_index_base,
-                                                reinterpret_cast<zoic_ray *>(cam->dRays.ptr), nullptr)) return s;
-    std::vector<zoic_ray> h(n);
-    ZOIC_HIP(hipMemcpy(h.data(), cam->dRays.ptr, n * sizeof(zoic_ray), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; ++i) {
-        zoic_camera_output &o = outputs[i];
-        const zoic_ray &r = h[i];
-        o.origin = zoic_vec3{r.ox, r.oy, r.oz};
-        o.dir = zoic_vec3{r.dx, r.dy, r.dz};
-        const float w = r.weight;
-        if (w == 0.0f) o.weight[0] = o.weight[1] = o.weight[2] = 0.0f;  // output.weight = 0.0f, zoic.cpp:1825/1952
-        else if (w != 1.0f) { o.weight[0] *= w; o.weight[1] *= w; o.weight[2] *= w; }  // exposure factor
-        if (r.flags & 1u) { o.dOdy = o.origin; o.dDdy = o.dir; }  // zoic.cpp:1974-1977
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    ContextLease lease(cam);
+    if (!lease) return fail(ZOIC_ERR_HIP, std::string("call context: ") + hipGetErrorString(lease.error()));
+    CallContext &C = *lease;
+    // Same two-stream pipeline as zoic_create_rays_host; the 32-byte records land in the context's pinned buffers and the
+    // host expands piece k into AtCameraOutput layout while piece k+1 is on the GPU.
+    const uint64_t piece = host_piece(n);
+    const size_t cap = static_cast<size_t>(std::min<uint64_t>(n, piece));
+    for (int b = 0; b < 2 && (b == 0 || n > piece); ++b) {
+        ZOIC_HIP(C.dInputs7[b].reserve(cap * 7));
+        ZOIC_HIP(C.dSamples[b].reserve(cap * 4));
+        ZOIC_HIP(C.dRays[b].reserve(cap));
+        ZOIC_HIP(C.hRays[b].reserve(cap * sizeof(zoic_ray)));
     }
-    return ZOIC_OK;
+    zoic_status status = ZOIC_OK;
+    uint64_t k = 0, prevOff = 0, prevM = 0;
+    int prevB = -1;
+    const auto expand_piece = [&](int b, uint64_t off, uint64_t m) -> hipError_t {
+        const hipError_t e = hipEventSynchronize(C.landed[b]);
+        if (e != hipSuccess) return e;
+        const zoic_ray *r = static_cast<const zoic_ray *>(C.hRays[b].host);
+        for (uint64_t i = 0; i < m; ++i) expand_record(r[i], outputs[off + i]);
+        return hipSuccess;
+    };
+    for (uint64_t off = 0; off < n && status == ZOIC_OK; off += piece, ++k) {
+        const int b = static_cast<int>(k & 1u);
+        const uint64_t m = std::min<uint64_t>(piece, n - off);
+        hipStream_t st = C.stream[b];
+        hipError_t e = hipMemcpyAsync(C.dInputs7[b].ptr, inputs + off, m * sizeof(zoic_camera_input), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = static_cast<hipError_t>(launch_pack_inputs(C.dInputs7[b].ptr, C.dSamples[b].ptr, m, st));
+        if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("H2D + pack: ") + hipGetErrorString(e)); break; }
+        status = launch_rays(cam, m, C.dSamples[b].ptr, nullptr, ray_index_base + off, C.dRays[b].ptr, st);
+        if (status != ZOIC_OK) break;
+        e = hipMemcpyAsync(C.hRays[b].host, C.dRays[b].ptr, m * sizeof(zoic_ray), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(C.landed[b], st);
+        if (e == hipSuccess && prevB >= 0) e = expand_piece(prevB, prevOff, prevM);   // overlaps this piece's GPU work
+        if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e)); break; }
+        prevB = b; prevOff = off; prevM = m;
+    }
+    if (status == ZOIC_OK && prevB >= 0) {
+        const hipError_t e = expand_piece(prevB, prevOff, prevM);
+        if (e != hipSuccess) status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+    }
+    if (status != ZOIC_OK) for (int b = 0; b < 2; ++b) (void)hipStreamSynchronize(C.stream[b]);   // nothing of ours left in flight
+    return status;
 }
 
 zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output, uint16_t tid)
 {
-    // camera_create_ray(node, input, output, tid): `tid` is unused by the reference as well (zoic.cpp:1752).
-    (void)tid;
-    return zoic_create_rays_arnold(cam, 1, input, output, 0);
+    // camera_create_ray(node, input, output, tid), zoic.cpp:1752.  The reference ignores `tid` and lets every render thread
+    // race on one global xor128 state; here each tid owns a retry stream that carries over from call to call, and tid 0's
+    // stream is the camera's own reference state (the one node_update's LUT build draws from), so a single-threaded
+    // sequence of update / create_ray calls reproduces the reference process draw for draw.
+    if (zoic_status s = check_ray_call(cam)) return s;
+    if (!input || !output) return fail(ZOIC_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    TidState *T = cam->tid_state(tid);
+    std::lock_guard<std::mutex> tidLock(T->m);
+    Rng &rng = tid == 0 ? cam->stream : T->rng;
+    ContextLease lease(cam);
+    if (!lease) return fail(ZOIC_ERR_HIP, std::string("call context: ") + hipGetErrorString(lease.error()));
+    CallContext &C = *lease;
+    // zero-copy: the kernel reads the sample and the stream state from, and writes the record to, mapped pinned memory
+    struct Block { float sample[4]; uint32_t rng[4]; zoic_ray ray; };
+    static_assert(sizeof(Block) == 64, "per-sample block");
+    Block *h = static_cast<Block *>(C.one.host);
+    Block *d = static_cast<Block *>(C.one.dev);
+    h->sample[0] = input->sx; h->sample[1] = input->sy; h->sample[2] = input->lensx; h->sample[3] = input->lensy;
+    h->rng[0] = rng.x; h->rng[1] = rng.y; h->rng[2] = rng.z; h->rng[3] = rng.w;
+    if (zoic_status s = launch_rays(cam, 1, d->sample, d->rng, 0, reinterpret_cast<RayRecord *>(&d->ray), C.stream[0])) return s;
+    ZOIC_HIP(hipStreamSynchronize(C.stream[0]));
+    const zoic_ray r = h->ray;
+    // every retry drew two numbers (zoic.cpp:1806 / 1881 / 1930), whether or not the kernel short-cut them
+    const uint32_t tries = (r.flags >> 1) & 31u;
+    for (uint32_t i = 0; i < 2u * tries; ++i) (void)xor128(rng);
+    expand_record(r, *output);
+    return ZOIC_OK;
+}
+
+int zoic_camera_reverse_ray(const zoic_camera *cam, const zoic_vec3 *Po, float fov, float *Ps, float *relative_time)
+{
+    // camera_reverse_ray, zoic.cpp:1992-1995: `return false;` -- nothing is written
+    (void)cam; (void)Po; (void)fov; (void)Ps; (void)relative_time;
+    return 0;
+}
+
+zoic_status zoic_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return fail(ZOIC_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return ZOIC_OK;
+    ZOIC_HIP(hipHostMalloc(out, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    return ZOIC_OK;
+}
+
+void zoic_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+zoic_status zoic_host_register(void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return fail(ZOIC_ERR_INVALID_ARGUMENT, "empty range");
+    ZOIC_HIP(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    return ZOIC_OK;
+}
+
+zoic_status zoic_host_unregister(void *p)
+{
+    if (!p) return fail(ZOIC_ERR_INVALID_ARGUMENT, "NULL pointer");
+    ZOIC_HIP(hipHostUnregister(p));
+    return ZOIC_OK;
 }
 
 zoic_status zoic_generate_samples_device(zoic_camera *cam, uint64_t n, uint64_t ray_index_base, uint32_t width, uint32_t height,
@@ -630,7 +969,8 @@ zoic_status zoic_generate_samples_device(zoic_camera *cam, uint64_t n, uint64_t 
     if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
     if (!d_samples || width == 0 || height == 0 || spp == 0) return fail(ZOIC_ERR_INVALID_ARGUMENT, "bad sample grid");
     if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera");
-    ZOIC_HIP(hipSetDevice(cam->device));
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
     if (int rc = launch_generate_samples(d_samples, ray_index_base, n, width, height, spp, seed, stream))
         return fail(ZOIC_ERR_HIP, std::string("sample kernel: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
     return ZOIC_OK;
@@ -643,8 +983,9 @@ zoic_status zoic_camera_get_counters(zoic_camera *cam, zoic_counters *out)
         out->succesRays = out->vignettedRays = 0; out->totalInternalReflection = cam->lens.precomputeTIR;
         return ZOIC_OK;
     }
-    ZOIC_HIP(hipSetDevice(cam->device));
-    ZOIC_HIP(hipDeviceSynchronize());
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    ZOIC_HIP(hipDeviceSynchronize());   // every stream of the device: launches of all threads are counted
     DeviceCounters c{};
     ZOIC_HIP(hipMemcpy(&c, cam->dCounters, sizeof(c), hipMemcpyDeviceToHost));
     out->succesRays = c.succes; out->vignettedRays = c.vignetted; out->totalInternalReflection = c.tir;
@@ -655,7 +996,9 @@ zoic_status zoic_camera_reset_counters(zoic_camera *cam)
 {
     if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
     if (cam->device == ZOIC_DEVICE_NONE) return ZOIC_OK;
-    ZOIC_HIP(hipSetDevice(cam->device));
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    ZOIC_HIP(hipDeviceSynchronize());
     ZOIC_HIP(hipMemset(cam->dCounters, 0, sizeof(DeviceCounters)));
     return ZOIC_OK;
 }
