@@ -68,3 +68,108 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path, oracle_lib):
     assert got.shape == (n, 8)
     assert np.array_equal(np.ascontiguousarray(got[:, :7].T).view(np.uint32), ref["planes"].view(np.uint32))
     assert np.array_equal(np.ascontiguousarray(got[:, 7]).view(np.uint32), ref["flags"].astype(np.uint32))
+
+
+def _oracle_generate(n_total):
+    """ray-record generator over global ray indices backed by the oracle (CPU tests); bench.py plugs ZoicCamera in here"""
+    import torch
+    import oracle
+    from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
+    c = CONFIGS["C2"]
+    oc = oracle.OracleCamera().update(**camera_params("C2"))
+
+    def generate(a, b):
+        s = synthetic_samples(b - a, c["width"], c["height"], c["spp"], seed=1, ray_index_base=a)
+        r = oc.create_rays(s, rng_states=ray_rng_states(b - a, 1, a))
+        rec = np.zeros((b - a, 8), np.float32)
+        rec[:, :7] = r["planes"].T
+        rec[:, 7] = r["flags"].astype(np.uint32).view(np.float32)
+        return torch.from_numpy(rec)
+    return generate
+
+
+def _pipelined_worker(rank, world, port, n, chunk_bytes, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from zoic_amd.sharding import ShardedFrame
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frame = ShardedFrame(n, dist, torch.device("cpu"), _oracle_generate(n), dst=0, chunk_bytes=chunk_bytes)
+    assert frame.run(gather=False) is None                       # compute-only leg of the bench: no exchange at all
+    for step in range(2):                                        # reusable across steps
+        full = frame.run(gather=True)
+    if rank == 0:
+        np.save(os.path.join(outdir, "payload.npy"), full.numpy())
+        np.save(os.path.join(outdir, "rounds.npy"), np.array([frame.rounds, len(frame.chunks[0]), len(frame.chunks[-1])]))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,chunk_bytes", [(2, 3000, 28 * 512), (3, 10_001, 28 * 1024), (2, 700, 64 << 20)])
+def test_pipelined_chunked_gather_equals_single_process(tmp_path, oracle_lib, world, n, chunk_bytes):
+    """ShardedFrame: slabs cut into sub-launch chunks, the 28-byte payload of chunk k posted (batch_isend_irecv) while
+    chunk k+1 is generated; ragged slabs, ragged last chunks, more rounds on some ranks than on others."""
+    import torch.multiprocessing as mp
+    from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_pipelined_worker, args=(world, port, n, chunk_bytes, str(tmp_path)), nprocs=world, join=True)
+    c = CONFIGS["C2"]
+    oc = oracle_lib.OracleCamera().update(**camera_params("C2"))
+    ref = oc.create_rays(synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1), rng_states=ray_rng_states(n, 1, 0))
+    got = np.load(tmp_path / "payload.npy")
+    assert got.shape == (n, 7)                                   # origin, dir, weight: the flag word is not gathered
+    assert np.array_equal(np.ascontiguousarray(got.T).view(np.uint32), ref["planes"].view(np.uint32))
+    rounds = np.load(tmp_path / "rounds.npy")
+    if chunk_bytes < (1 << 20):
+        assert rounds[0] > 1                                     # really chunked
+
+
+def _gpu_worker(rank, world, port, n, outdir):
+    """both ranks drive cuda:0 through ZoicCamera (one GPU on the test box); the exchange runs over gloo on host tensors"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from zoic_amd import PRECISION_STRICT, ZoicCamera
+    from zoic_amd.sharding import ShardedFrame
+    from zoic_amd.workloads import CONFIGS, camera_params
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = CONFIGS["C2"]
+    cam = ZoicCamera(0)
+    cam.update(**camera_params("C2"))
+    cam.set_precision(PRECISION_STRICT)
+
+    def generate(a, b):
+        s = cam.generate_samples(b - a, c["width"], c["height"], c["spp"], seed=1, ray_index_base=a)
+        return cam.create_rays(s, ray_index_base=a)["rays"].cpu()
+    full = ShardedFrame(n, dist, torch.device("cpu"), generate, dst=0, chunk_bytes=28 * 40_000).run(gather=True)
+    if rank == 0:
+        np.save(os.path.join(outdir, "payload_gpu.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+    cam.close()
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_frame_through_the_hip_path(gpu, tmp_path, oracle_lib):
+    """The same ShardedFrame with ZoicCamera (the HIP path) as the generator: two processes, ray-index slabs, chunked
+    gather; bit-identical to the oracle's unsharded frame."""
+    import torch.multiprocessing as mp
+    from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
+    n = 250_000
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_gpu_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    c = CONFIGS["C2"]
+    oc = oracle_lib.OracleCamera().update(**camera_params("C2"))
+    ref = oc.create_rays(synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1), rng_states=ray_rng_states(n, 1, 0), threads=8)
+    got = np.load(tmp_path / "payload_gpu.npy")
+    assert np.array_equal(np.ascontiguousarray(got.T).view(np.uint32), ref["planes"].view(np.uint32))

@@ -1,11 +1,18 @@
 """Multi-GPU layout of the hot path: one process per GPU, the frame's samples split into contiguous, tile-aligned
 slabs of the global ray index, no data-path collective while rays are generated (every ray depends only on its own
 sample and on read-only tables).  Per-ray retry streams are keyed by the GLOBAL ray index, so a sharded frame is
-bit-identical to the single-GPU frame.  The one optional exchange is a gather of the finished ray slabs on a root
-rank (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU in the tests).
+bit-identical to the single-GPU frame.  The one exchange is the gather of the finished ray slabs on a root rank
+(torch.distributed: RCCL over xGMI on GPUs, gloo on CPU in the tests).
+
+The gather is pipelined against the trace: a rank cuts its slab into sub-launches of about `chunk_bytes`
+of payload; as soon as sub-launch k is queued, its 28-byte payload (origin, dir, weight -- the flag word stays home)
+is posted to the root on the communication stream while sub-launch k+1 traces.  xGMI is point to point: every
+peer -> root transfer rides its own link, so the root ingests on up to 7 links at once; all sends/recvs of one round
+are posted as ONE batch_isend_irecv group (a single ncclGroupStart/End on RCCL).
 """
 
 TILE = 256  # rays per workgroup tile; slabs are aligned to it
+PAYLOAD_FLOATS = 7  # ox oy oz dx dy dz weight: what SURVEY 8(e) gathers (28 B/ray); column 7 of a record is the flag word
 
 
 def slab_for_rank(n_total, rank, world, tile=TILE):
@@ -22,10 +29,20 @@ def all_slabs(n_total, world, tile=TILE):
     return [slab_for_rank(n_total, r, world, tile) for r in range(world)]
 
 
+def chunks_of_slab(lo, hi, chunk_rays, tile=TILE):
+    """Cut [lo, hi) into pieces of about chunk_rays rays (tile aligned, the last one ragged)."""
+    chunk_rays = max(tile, (chunk_rays // tile) * tile)
+    out, a = [], lo
+    while a < hi:
+        b = min(a + chunk_rays, hi)
+        out.append((a, b))
+        a = b
+    return out
+
+
 def gather_rays(rays, n_total, dist, dst=0, tile=TILE):
-    """Gather every rank's (n_r, k) ray-record tensor on `dst`; returns (n_total, k) there, None elsewhere.
-    Slabs may differ in size by one tile, so the exchange is grouped point-to-point (the RCCL-friendly form of a
-    gatherv: each peer->root transfer rides its own xGMI link)."""
+    """Blocking whole-slab gather (round-1 form; kept for the CPU tests and as the un-overlapped baseline):
+    every rank's (n_r, k) tensor lands in an (n_total, k) tensor on `dst`; None elsewhere."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     slabs = all_slabs(n_total, world, tile)
@@ -33,15 +50,91 @@ def gather_rays(rays, n_total, dist, dst=0, tile=TILE):
         full = torch.empty((n_total,) + tuple(rays.shape[1:]), dtype=rays.dtype, device=rays.device)
         lo, hi = slabs[dst]
         full[lo:hi] = rays
-        reqs = []
-        for r, (a, b) in enumerate(slabs):
-            if r == dst or b <= a:
-                continue
-            reqs.append(dist.irecv(full[a:b], src=r))  # contiguous row range: received in place
-        for q in reqs:
+        ops = [dist.P2POp(dist.irecv, full[a:b], r) for r, (a, b) in enumerate(slabs) if r != dst and b > a]
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         return full
     lo, hi = slabs[rank]
     if hi > lo:
-        dist.send(rays.contiguous(), dst=dst)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, rays.contiguous(), dst)]):
+            q.wait()
     return None
+
+
+class ShardedFrame:
+    """One frame of n_total samples rendered by `world` ranks in ray-index slabs and gathered on `dst`.
+
+    generate(chunk)        -> callable that produces the (m, 8) ray records of global rays [a, b) on this rank
+                              (the HIP path on a GPU; the tests plug the oracle in on CPU)
+    The root's `full` tensor is (n_total, 7) payload.  Reusable across steps (buffers are allocated once)."""
+
+    def __init__(self, n_total, dist, device, generate, dst=0, chunk_bytes=None, tile=TILE, payload_floats=PAYLOAD_FLOATS,
+                 min_chunk_bytes=64 << 20, chunks_per_slab=4):
+        import torch
+        self.torch, self.dist, self.device, self.generate, self.dst = torch, dist, device, generate, dst
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.n_total, self.k = n_total, payload_floats
+        self.slabs = all_slabs(n_total, self.world, tile)
+        if chunk_bytes is None:
+            # A sub-launch has ~0.1 ms of fixed cost (start-up + the tail of its unluckiest rays) against ~0.03 ms of
+            # trace per 64 MB of payload, so chunks are as large as overlap allows: a slab is cut into `chunks_per_slab`
+            # pieces, never smaller than 64 MB of payload (SURVEY 8e's floor).
+            slab_bytes = 4 * payload_floats * max(b - a for a, b in self.slabs)
+            chunk_bytes = max(min_chunk_bytes, (slab_bytes + chunks_per_slab - 1) // chunks_per_slab)
+        self.chunk_bytes = chunk_bytes
+        chunk_rays = max(tile, chunk_bytes // (4 * payload_floats))
+        # every rank cuts its slab the same way, so the root knows each peer's message sizes without a handshake
+        self.chunks = [chunks_of_slab(a, b, chunk_rays, tile) for a, b in self.slabs]
+        self.rounds = max(len(c) for c in self.chunks)
+        lo, hi = self.slabs[self.rank]
+        self.full = torch.empty((n_total, self.k), dtype=torch.float32, device=device) if self.rank == dst else None
+        # staging for the payload of the chunks in flight (two buffers: chunk k is on the wire while k+1 is packed)
+        biggest = max((b - a for a, b in self.chunks[self.rank]), default=0)
+        self.stage = [torch.empty((biggest, self.k), dtype=torch.float32, device=device) for _ in range(2)] if self.rank != dst else None
+        self.cuda = device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=device) if self.cuda else None
+
+    def run(self, gather=True):
+        """Render this rank's slab chunk by chunk; with gather=True the payload of chunk k travels while chunk k+1 is
+        traced.  Returns the root's full (n_total, 7) tensor (None on the other ranks, or when gather=False)."""
+        torch, dist = self.torch, self.dist
+        mine = self.chunks[self.rank]
+        pending = []
+        for k in range(self.rounds):
+            rec = None
+            if k < len(mine):
+                a, b = mine[k]
+                rec = self.generate(a, b)               # queued on the current (compute) stream, asynchronous on a GPU
+            if not gather:
+                continue
+            ops = []
+            if self.rank == self.dst:
+                if rec is not None:
+                    self.full[a:b].copy_(rec[:, :self.k])
+                for r in range(self.world):
+                    if r != self.dst and k < len(self.chunks[r]):
+                        ra, rb = self.chunks[r][k]
+                        ops.append(dist.P2POp(dist.irecv, self.full[ra:rb], r))
+            elif rec is not None:
+                buf = self.stage[k & 1][: b - a]
+                if self.cuda and len(pending) >= 2:
+                    for q in pending.pop(0):            # the send that used this staging buffer two rounds ago
+                        q.wait()
+                buf.copy_(rec[:, :self.k])             # 32-byte records -> 28-byte payload, on the compute stream
+                ops.append(dist.P2POp(dist.isend, buf, self.dst))
+            if ops:
+                if self.cuda:
+                    # post the round on the communication stream, behind the compute work queued so far: RCCL moves
+                    # chunk k while the next iteration's kernel runs on the compute stream
+                    self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(self.comm_stream):
+                        pending.append(dist.batch_isend_irecv(ops))
+                else:
+                    pending.append(dist.batch_isend_irecv(ops))
+        for reqs in pending:
+            for q in reqs:
+                q.wait()
+        if gather and self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        return self.full if gather else None
