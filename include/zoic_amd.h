@@ -55,7 +55,12 @@ typedef enum zoic_lens_model { ZOIC_THINLENS = 0, ZOIC_RAYTRACED = 1, ZOIC_LENS_
 /* arithmetic mode of the kernels */
 typedef enum zoic_precision {
     ZOIC_PRECISION_STRICT = 0, /* the reference's operation order, no FMA contraction, its f64 intermediates: bit-exact vs the CPU oracle */
-    ZOIC_PRECISION_FAST = 1    /* same algorithm, f32 only, FMA/rsq, redundant normalisations removed: direction RMSE < 1e-5 */
+    ZOIC_PRECISION_FAST = 1,   /* same algorithm, f32 only, FMA/rsq, redundant normalisations removed: direction RMSE < 1e-5.
+                                  Decision-safe: every accept/reject decision too close to call in this arithmetic is re-taken
+                                  in STRICT arithmetic (a second kernel over the few rays concerned), so try counts, weights,
+                                  flags and counters are the reference's; only low-order bits of origin/direction differ */
+    ZOIC_PRECISION_FAST_UNCHECKED = 2 /* FAST without the decision check (A/B; decisions flip where the reference's own f32
+                                         rounding noise decides, ~1e-5 ... 1e-3 of the rays depending on the lens) */
 } zoic_precision;
 
 #define ZOIC_MAX_LENS_SURFACES 32

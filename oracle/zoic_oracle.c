@@ -418,6 +418,20 @@ static void compute_lens_centers(zo_lensdata *ld)
 }
 
 /* --------------------------------------------------------------- optics */
+/* Diagnostic hook (tests / tools only; never alters a result): while g_margin_probe points at a record, the three
+ * accept/reject decisions of traceThroughLensElements note how close each call was -- the smallest |relative margin|
+ * seen, the interface it occurred at and its kind (0 housing/stop clip :1114-1115, 1 sphere miss :980, 2 total internal
+ * reflection :1019).  Used to calibrate the guard bands of the product's decision-safe FAST mode. */
+static __thread zo_margin_probe *g_margin_probe = NULL;
+static __thread int g_probe_iface = 0;
+static inline void probe_note(float value, float limit, int kind)
+{
+    zo_margin_probe *p = g_margin_probe;
+    if (!p) return;
+    float m = fabsf(value - limit) / (fabsf(limit) > 0.0f ? fabsf(limit) : 1.0f);
+    if (m < p->min_rel_margin) { p->min_rel_margin = m; p->iface = g_probe_iface; p->kind = kind; }
+}
+
 /* raySphereIntersection, zoic.cpp:973-995 */
 static inline int raySphereIntersection(zo_v3 *hit_point, zo_v3 ray_direction, zo_v3 ray_origin, zo_v3 sphere_center,
                                         float sphere_radius, int reverse, int tracingRealRays)
@@ -427,6 +441,7 @@ static inline int raySphereIntersection(zo_v3 *hit_point, zo_v3 ray_direction, z
     float tca = ai_v3_dot(L, ray_direction);
     float radius2 = sphere_radius * sphere_radius;
     float d2 = ai_v3_dot(L, L) - (tca * tca);
+    if (tracingRealRays) probe_note(d2, radius2, 1);
     if (tracingRealRays && (d2 > radius2)) return 0;
     float thc = sqrtf(fabsf(radius2 - d2));
     float sign = (sphere_radius < 0.0f ? -1.0f : 1.0f);
@@ -453,6 +468,7 @@ static inline int calculateTransmissionVector(zo_v3 *ray_direction, float ior1, 
     if (ior2 == 1.0) eta = ior1; else eta = ior1 / ior2;                /* :1013 */
     float c1 = -ai_v3_dot(incidentVector, normalVector);
     float cs2 = (float)((double)(eta * eta) * (1.0 - (double)(c1 * c1))); /* :1016 */
+    if (tracingRealRays && (ior1 > ior2)) probe_note(cs2, 1.0f, 2);
     if ((tracingRealRays) && (ior1 > ior2) && ((double)cs2 > 1.0)) return 0; /* :1019 */
     float k = (float)((double)(eta * c1) - sqrt(fabs(1.0 - (double)cs2))); /* :1023, narrowed by operator*(float) */
     *ray_direction = v3_add(v3_mulf(incidentVector, eta), v3_mulf(normalVector, k));
@@ -518,12 +534,18 @@ static inline int traceThroughLensElements(zo_v3 *ray_origin, zo_v3 *ray_directi
     zo_v3 hit_point, hit_point_normal, sphere_center;
     const int n = ld->lensCount;
     for (int i = 0; i < n; i++) {
+        g_probe_iface = i;
         sphere_center.x = 0.0f; sphere_center.y = 0.0f; sphere_center.z = ld->lenses[i].center;
         if (!raySphereIntersection(&hit_point, *ray_direction, *ray_origin, sphere_center, ld->lenses[i].curvature, 0, 1))
             return 0;
         float hitPoint2 = hit_point.x * hit_point.x + hit_point.y * hit_point.y;
         /* :1114-1115 -- the housing clip is evaluated in f64, the user-aperture clip in f32 */
         double half = (double)ld->lenses[i].aperture * 0.5;
+        if (g_margin_probe) {
+            float lim = (float)(half * half);
+            if (i == ld->apertureElement && ld->userApertureRadius * ld->userApertureRadius < lim) lim = ld->userApertureRadius * ld->userApertureRadius;
+            probe_note(hitPoint2, lim, 0);
+        }
         if (((double)hitPoint2 > half * half)
             || ((i == ld->apertureElement) && (hitPoint2 > (ld->userApertureRadius * ld->userApertureRadius))))
             return 0;
@@ -944,6 +966,23 @@ void zo_create_ray(zo_camera *camera, const zo_input *input, zo_output *output, 
         for (int k = 0; k < 3; ++k) output->weight[k] *= 1.0f / (1.0f + e2);
     }
     if (tries_out) *tries_out = tries | (lut_miss << 8);
+}
+
+/* diagnostic: the closest accept/reject call of every decision ray i's evaluation took (see g_margin_probe) */
+void zo_create_rays_probe(zo_camera *cam, size_t n, const float *in4, const uint32_t *rng_states, zo_margin_probe *out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        zo_input in = { in4[4 * i], in4[4 * i + 1], 0, 0, in4[4 * i + 2], in4[4 * i + 3], 0 };
+        zo_output o; memset(&o, 0, sizeof(o));
+        o.weight[0] = o.weight[1] = o.weight[2] = 1.0f;
+        zo_rng r = { rng_states[4 * i], rng_states[4 * i + 1], rng_states[4 * i + 2], rng_states[4 * i + 3] };
+        out[i].min_rel_margin = 3.0e38f; out[i].iface = -1; out[i].kind = -1;
+        g_margin_probe = &out[i];
+        int tries = 0;
+        zo_create_ray(cam, &in, &o, &r, &tries);
+        g_margin_probe = NULL;
+        out[i].tries = tries & 0xff;
+    }
 }
 
 /* ------------------------------------------------------------ batch driver */

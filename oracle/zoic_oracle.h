@@ -140,6 +140,11 @@ void  zo_bokeh_sample(const zo_camera *, float u1, float u2, float *dx, float *d
  * writes the number of recorded hits to *nhits. */
 int   zo_trace_record(zo_camera *, zo_v3 *origin, zo_v3 *dir, zo_v3 *hits, int *nhits);
 
+/* diagnostic (tools/tests only): how close the closest accept/reject decision of a ray's evaluation was.
+ * kind: 0 housing/stop clip (zoic.cpp:1114-1115), 1 sphere miss (:980), 2 total internal reflection (:1019) */
+typedef struct zo_margin_probe { float min_rel_margin; int iface, kind, tries; } zo_margin_probe;
+void zo_create_rays_probe(zo_camera *cam, size_t n, const float *in4, const uint32_t *rng_states, zo_margin_probe *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,11 @@ from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_count,
 pytestmark = pytest.mark.gpu
 
 DIR_RMSE_TOL = 1e-5        # BASELINE.json north_star: "ray-direction RMSE <1e-5 vs CPU reference"
-FLIP_TOL = float(os.environ.get("ZOIC_FLIP_TOL", "2e-3"))            # decision flips of fast mode; the reference's own FMA/no-FMA builds flip ~2e-5
+# Decision flips of FAST (the decision-safe mode: rays whose stop clip is too close to call are re-evaluated in STRICT
+# arithmetic).  Measured 0 ... 4e-7 on C2-C5 (33 M rays each); the reference's own FMA / no-FMA builds flip 5e-6 ... 3e-4
+# of the same rays (DESIGN.md "decision-safe fast mode").  A constant, not a knob.
+FLIP_TOL = 5e-5
+UNCHECKED_FLIP_TOL = 2e-3   # ZOIC_PRECISION_FAST_UNCHECKED (round 1's fast mode, kept for A/B): flips where the reference's own rounding decides
 
 
 def bits(a):

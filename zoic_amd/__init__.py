@@ -4,8 +4,8 @@ The product is libzoic_amd.so (HIP kernels + C-ABI, include/zoic_amd.h).  This p
 mirror of the reference's Arnold node interface over that C-ABI; it contains no ray arithmetic and no CPU
 fallback -- if the library is missing, importing the camera raises.
 """
-from ._capi import PRECISION_FAST, PRECISION_STRICT, RAYTRACED, THINLENS, ZoicLibraryError  # noqa: F401
+from ._capi import PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, RAYTRACED, THINLENS, ZoicLibraryError  # noqa: F401
 from .camera import DEFAULTS, PinnedArray, ZoicCamera, ZoicError, lens_path  # noqa: F401
 
 __all__ = ["ZoicCamera", "PinnedArray", "ZoicError", "ZoicLibraryError", "DEFAULTS", "lens_path", "RAYTRACED", "THINLENS",
-           "PRECISION_STRICT", "PRECISION_FAST"]
+           "PRECISION_STRICT", "PRECISION_FAST", "PRECISION_FAST_UNCHECKED"]

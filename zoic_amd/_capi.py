@@ -14,7 +14,7 @@ MAX_LENS_SURFACES = 32
 LUT_ENTRIES = 32
 
 THINLENS, RAYTRACED, LENS_NONE = 0, 1, 2
-PRECISION_STRICT, PRECISION_FAST = 0, 1
+PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_UNCHECKED = 0, 1, 2
 
 STATUS_NAMES = ["ZOIC_OK", "ZOIC_ERR_INVALID_ARGUMENT", "ZOIC_ERR_LENS_PATH", "ZOIC_ERR_LENS_COLUMNS",
                 "ZOIC_ERR_LENS_PARSE", "ZOIC_ERR_MULTI_APERTURE", "ZOIC_ERR_NO_APERTURE", "ZOIC_ERR_TOO_MANY_LENSES",

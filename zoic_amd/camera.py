@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 from . import _capi
-from ._capi import PRECISION_FAST, PRECISION_STRICT, RAYTRACED, THINLENS  # noqa: F401
+from ._capi import PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, RAYTRACED, THINLENS  # noqa: F401
 
 LENS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lenses")
 

@@ -122,6 +122,8 @@ struct LaunchSlot {
     unsigned int *cursor = nullptr;
     hipEvent_t done = nullptr;
     bool recorded = false;
+    hipStream_t lastStream = nullptr;   // a launch on the same stream is ordered behind the previous one: no event wait needed
+    DeviceBuffer<uint32_t> redo;        // decision-safe FAST: the STRICT kernel's work list, one dword per sample of the launch
 };
 
 // Private scratch of ONE host-buffer call in flight: leased from the camera's pool for the duration of the call.
@@ -483,19 +485,43 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
     const int model = cam->params.p.lensModel;
     if (model != ZOIC_RAYTRACED && model != ZOIC_THINLENS)
         return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
-    LaunchSlot &slot = cam->slots[cam->nextSlot.fetch_add(1u, std::memory_order_relaxed) % kLaunchSlots];
-    std::lock_guard<std::mutex> lk(slot.m);
-    // the slot's previous user (another stream, maybe another thread) must be done before its cursors are reset
-    if (slot.recorded) ZOIC_HIP(hipStreamWaitEvent(stream, slot.done, 0));
-    const bool fast = cam->precision == ZOIC_PRECISION_FAST;
+    const int mode = cam->precision == ZOIC_PRECISION_STRICT ? 0 : (cam->precision == ZOIC_PRECISION_FAST ? 1 : 2);
+    const bool needList = model == ZOIC_RAYTRACED && mode == 1;
+    // Slot choice.  A caller that keeps launching on one stream keeps ONE slot (its launches are ordered anyway, and the
+    // slot's work-list buffer is allocated once); otherwise the first idle slot; with all 64 busy, the next in turn,
+    // behind its previous user's completion event.
+    LaunchSlot *slot = nullptr;
+    std::unique_lock<std::mutex> lk;
+    for (unsigned pass = 0; pass < 2 && !slot; ++pass)
+        for (unsigned i = 0; i < kLaunchSlots && !slot; ++i) {
+            LaunchSlot &c = cam->slots[i];
+            std::unique_lock<std::mutex> t(c.m, std::try_to_lock);
+            if (!t.owns_lock()) continue;
+            const bool mine = c.recorded && c.lastStream == stream;
+            if (pass == 0 ? mine : (!c.recorded || hipEventQuery(c.done) == hipSuccess)) { slot = &c; lk = std::move(t); }
+        }
+    if (!slot) {
+        slot = &cam->slots[cam->nextSlot.fetch_add(1u, std::memory_order_relaxed) % kLaunchSlots];
+        lk = std::unique_lock<std::mutex>(slot->m);
+    }
+    (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error of this call
+    if (slot->recorded && slot->lastStream != stream) ZOIC_HIP(hipStreamWaitEvent(stream, slot->done, 0));
+    const size_t listEntries = static_cast<size_t>(n < (1ull << 31) ? n : (1ull << 31));
+    if (needList && slot->redo.cap < listEntries) {
+        // growing the list frees the old one: the slot's previous launch must be over (rare: first use / a larger batch)
+        if (slot->recorded) ZOIC_HIP(hipEventSynchronize(slot->done));
+        ZOIC_HIP(slot->redo.reserve(listEntries));
+    }
     int rc;
     if (model == ZOIC_RAYTRACED)
-        rc = launch_kolb_rays(cam->kolb, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot.cursor, fast, stream);
+        rc = launch_kolb_rays(cam->kolb, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, mode,
+                              needList ? slot->redo.ptr : nullptr, stream);
     else
-        rc = launch_thin_rays(cam->thin, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot.cursor, fast, stream);
+        rc = launch_thin_rays(cam->thin, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, mode != 0, stream);
     if (rc != 0) return fail(ZOIC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-    ZOIC_HIP(hipEventRecord(slot.done, stream));
-    slot.recorded = true;
+    ZOIC_HIP(hipEventRecord(slot->done, stream));
+    slot->recorded = true;
+    slot->lastStream = stream;
     return ZOIC_OK;
 }
 
@@ -615,7 +641,10 @@ void zoic_camera_destroy(zoic_camera *cam)
         (void)hipDeviceSynchronize();   // launches the caller left in flight still read the tables and cursors freed below
         for (auto &c : cam->contexts) c->release();
         cam->contexts.clear(); cam->freeContexts.clear();
-        for (unsigned i = 0; i < kLaunchSlots; ++i) if (cam->slots[i].done) (void)hipEventDestroy(cam->slots[i].done);
+        for (unsigned i = 0; i < kLaunchSlots; ++i) {
+            if (cam->slots[i].done) (void)hipEventDestroy(cam->slots[i].done);
+            cam->slots[i].redo.release();
+        }
         cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release(); cam->dBokehCells.release();
         cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release();
         if (cam->dProbeTir) (void)hipFree(cam->dProbeTir);
@@ -650,7 +679,8 @@ zoic_status zoic_camera_set_lens_text(zoic_camera *cam, const char *text, size_t
 
 zoic_status zoic_camera_set_precision(zoic_camera *cam, zoic_precision mode)
 {
-    if (!cam || (mode != ZOIC_PRECISION_STRICT && mode != ZOIC_PRECISION_FAST)) return fail(ZOIC_ERR_INVALID_ARGUMENT, "bad precision");
+    if (!cam || (mode != ZOIC_PRECISION_STRICT && mode != ZOIC_PRECISION_FAST && mode != ZOIC_PRECISION_FAST_UNCHECKED))
+        return fail(ZOIC_ERR_INVALID_ARGUMENT, "bad precision");
     cam->precision = mode;
     return ZOIC_OK;
 }

@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "optics.hpp"
 
 #pragma clang fp contract(fast)
@@ -60,6 +62,43 @@ __device__ __forceinline__ float atan2_f32(float y, float x)
     return copysignf(r, y);
 }
 
+// The per-surface constants are wave-uniform kernel arguments: read through a pointer in the CONSTANT address space they
+// stay s_loads (SGPR operands).  The persistent pass loop re-derives this pointer every pass behind an empty asm
+// (launder_table): otherwise LLVM hoists all NS x 10 loads out of the pass loop as loop invariants, runs out of SGPRs and
+// spills them to VGPR lanes -- every constant then costs a v_readlane per use (measured: 568 v_readlane + VGPR scratch
+// spills in the decision-safe kernel, -25 % throughput) instead of a scalar-cache hit.
+#ifndef ZOIC_GUARD_PIN
+#define ZOIC_GUARD_PIN 1
+#endif
+typedef const FastSurface __attribute__((address_space(4))) *FastSurfaceTable;
+// The KolbTable is the FIRST kernel argument of every Kolb kernel (offset 0 of the kernarg segment): its FastSurface array
+// is addressed from the kernarg base.  (Deriving the pointer from &T instead makes the by-value argument's address escape
+// and LLVM copies parts of it to scratch.)
+__device__ __forceinline__ FastSurfaceTable kernarg_fast_surfaces()
+{
+    typedef const char __attribute__((address_space(4))) *KernargBytes;
+    return (FastSurfaceTable)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KolbTable, fsurf));
+}
+__device__ __forceinline__ FastSurfaceTable launder_table(FastSurfaceTable t)
+{
+    asm volatile("" : "+s"(t));
+    return t;
+}
+template <bool PIN = true>
+__device__ __forceinline__ FastSurface load_surface(FastSurfaceTable t, int i)
+{
+    if constexpr (PIN) asm volatile("" : "+s"(t));   // the loads of interface i are issued here, not hoisted to the top of the pass
+    FastSurface S;
+    S.center = t[i].center; S.radius2 = t[i].radius2; S.sign = t[i].sign; S.housing2 = t[i].housing2; S.invRadius = t[i].invRadius;
+    S.eta = t[i].eta; S.etaInvAbsR = t[i].etaInvAbsR; S.e2InvR2 = t[i].e2InvR2; S.oneMinusEta2 = t[i].oneMinusEta2;
+    S.bandHousing = t[i].bandHousing; S.pad0 = S.pad1 = 0.0f;
+    return S;
+}
+
+// Decision-safe mode: only ill-conditioned interfaces carry a guard band (bandHousing > 0, set by the host: in practice the
+// stop, see lens_system.cpp fill_surfaces); the test is a wave-uniform scalar branch, so well-conditioned interfaces pay nothing.
+__device__ __forceinline__ bool surface_is_guarded(const FastSurface &S) { return __builtin_bit_cast(int, S.bandHousing) > 0; }
+
 __device__ __forceinline__ float uniform_f32(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
@@ -71,7 +110,7 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
     r.center = uniform_f32(s.center); r.radius2 = uniform_f32(s.radius2); r.sign = uniform_f32(s.sign);
     r.housing2 = uniform_f32(s.housing2); r.invRadius = uniform_f32(s.invRadius); r.eta = uniform_f32(s.eta);
     r.etaInvAbsR = uniform_f32(s.etaInvAbsR); r.e2InvR2 = uniform_f32(s.e2InvR2); r.oneMinusEta2 = uniform_f32(s.oneMinusEta2);
-    r.pad0 = r.pad1 = r.pad2 = 0.0f;
+    r.bandHousing = uniform_f32(s.bandHousing); r.pad0 = r.pad1 = 0.0f;
     return r;
 }
 
@@ -86,7 +125,7 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
 //
 // One interface of the fast trace.  Returns 0 = passed, 1 = clipped (o, u untouched), 2 = total internal reflection
 // (o advanced, u untouched) -- the two partial states the reference can leave.
-__device__ __forceinline__ int fast_interface(const FastSurface &S, bool isStop, float userAperture2, V3 &o, V3 &u)
+__device__ __forceinline__ int fast_interface(const FastSurface &S, bool isStop, float userAperture2, V3 &o, V3 &u, bool *near = nullptr)
 {
     const float Lz = S.center - o.z;
     const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
@@ -97,9 +136,10 @@ __device__ __forceinline__ int fast_interface(const FastSurface &S, bool isStop,
     const V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
     const float h2 = hit.x * hit.x + hit.y * hit.y;
     const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
+    const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
+    if (near) *near = surface_is_guarded(S) && fabsf(h2 - S.housing2) < S.bandHousing;
     if (clipped) return 1;
     o = hit;
-    const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
     if (oneMinusCs2 < 0.0f) return 2;                       // cs2 > 1 (only reachable when eta > 1)
     const float k = thc * S.etaInvAbsR - fsqrt_fast(oneMinusCs2);
     const float kr = k * S.invRadius;                       // k * N = kr * (c - hit)
@@ -123,9 +163,26 @@ __device__ __forceinline__ bool interface0_clear_fast(const FastSurface &S, V3 o
     return !((d2 > S.radius2) | (h2 > S.housing2));
 }
 
+// The same test for the decision-safe mode: `near` is set when the housing decision lies inside its guard band (tables.hpp).
+__device__ __forceinline__ bool interface0_clear_fast_guard(const FastSurface &S, V3 o, V3 d, bool &near)
+{
+    const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
+    const V3 u{d.x * inv, d.y * inv, d.z * inv};
+    const float Lz = S.center - o.z;
+    const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
+    const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
+    const float w = fabsf(S.radius2 - d2);
+    const float thc = fsqrt_fast(w);
+    const float t = tca + thc * S.sign;
+    const float hx = o.x + u.x * t, hy = o.y + u.y * t;
+    const float h2 = hx * hx + hy * hy;
+    near = fabsf(h2 - S.housing2) < S.bandHousing;
+    return !((d2 > S.radius2) | (h2 > S.housing2));
+}
+
 // Rolled, branchy trace for any interface count.  It leaves exactly the partial state of the reference on every exit
 // path, so it is also what finishes rays that ran out of tries in the predicated kernel below.
-__device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+__device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool *unsure = nullptr)
 {
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
     V3 u{d.x * inv, d.y * inv, d.z * inv};
@@ -138,7 +195,9 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
         const int iu = __builtin_amdgcn_readfirstlane(i);
         const FastSurface S = uniform_surface(Snext);
         Snext = T.fsurf[(iu + 1 < n) ? iu + 1 : iu];
-        const int r = fast_interface(S, iu == T.apertureElement, T.userAperture2, o, u);
+        bool near = false;
+        const int r = fast_interface(S, iu == T.apertureElement, T.userAperture2, o, u, unsure ? &near : nullptr);
+        if (unsure) *unsure |= near;
         if (r != 0) { if (r == 2) ++tirCount; ok = false; break; }
         refracted = true;
         if (++i == n) break;
@@ -157,19 +216,23 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
 // every second interface leaves the trace as soon as no lane is alive (heavily vignetted passes).
 // Returns alive; o/u are the exit point and unit direction for alive lanes (unspecified for dead ones -- rays that
 // finish dead get their reference partial state from trace_lens_fast_rolled).
-template <int NS>
-__device__ __forceinline__ bool trace_lens_fast_pred(const FastSurface *__restrict__ surf, V3 &o, V3 &d, uint32_t &tirCount, bool alive0)
+// GUARD (decision-safe mode): `unsure` collects, for lanes still alive at a guarded interface, whether its clip decision
+// lies inside the guard band.
+template <int NS, bool GUARD = false>
+__device__ __forceinline__ bool trace_lens_fast_pred(FastSurfaceTable surf, V3 &o, V3 &d, uint32_t &tirCount, bool alive0,
+                                                     bool *unsureOut = nullptr)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
     V3 u{d.x * inv, d.y * inv, d.z * inv};
     bool alive = alive0, tirSeen = false;   // alive0: lanes without a candidate ride along dead
+    bool unsure = false;
     bool anyAlive = true;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;   // wave-uniform early out, every 2nd interface
         if (!anyAlive) continue;
-        const FastSurface S = surf[i];
+        const FastSurface S = load_surface<GUARD && (ZOIC_GUARD_PIN != 0)>(surf, i);
         const float Lz = S.center - o.z;
         const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
         const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
@@ -181,6 +244,9 @@ __device__ __forceinline__ bool trace_lens_fast_pred(const FastSurface *__restri
         const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
         const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
         const bool tirHere = oneMinusCs2 < 0.0f;
+        if constexpr (GUARD) {
+            unsure |= alive & (fabsf(h2 - S.housing2) < S.bandHousing);   // never true on unguarded interfaces (band 0): no branch
+        }
         tirSeen |= alive & !clipped & tirHere;                  // counted only by rays that reached the refraction
         alive &= !clipped & !tirHere;
         const float k = thc * S.etaInvAbsR - fsqrt_fast(fabsf(oneMinusCs2));
@@ -189,6 +255,7 @@ __device__ __forceinline__ bool trace_lens_fast_pred(const FastSurface *__restri
     }
     tirCount += tirSeen ? 1u : 0u;
     d = u;
+    if constexpr (GUARD) *unsureOut = unsure;
     return alive;
 }
 

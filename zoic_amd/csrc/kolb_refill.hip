@@ -26,6 +26,7 @@
 // window prefetch + record flush -> trace -> finish (park).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "kolb_device.hpp"
@@ -60,12 +61,51 @@ __device__ unsigned long long g_regionCycles[8];
 #define ZOIC_RT_FLUSH
 #endif
 
-template <bool STRICT, int NS>
-__device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
-                                                 const uint4 *__restrict__ rngStates, uint64_t rayBase, uint32_t n,
-                                                 RayRecord *__restrict__ out, DeviceCounters *counters,
-                                                 unsigned int *__restrict__ workCursor, uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching)
+// Kernel arguments that only rare paths read (chunk claim, first retry, work-list flush, exit) are fetched from the kernarg
+// segment where they are used instead of living in SGPRs for the whole kernel: the pass loop carries ~60 scalars, the
+// budget is 94, and what does not fit is spilled to VGPR lanes and paid for with a v_readlane per use inside the trace.
+// RefillArgs mirrors the kernels' parameter list (HIP lays kernel arguments out like a C struct; offsets checked against the
+// code object's metadata, tools/isa_mix.py).
+struct RefillArgs {
+    KolbTable T; BokehTables B; const float4 *samples; const uint4 *rngStates; uint64_t rayBase; uint32_t n; RayRecord *out;
+    DeviceCounters *counters; unsigned int *workCursor; uint32_t ldsWords, chunkRays, chunksPerPart, minSearching; uint32_t *redoList;
+    unsigned int *redoCount;
+};
+template <class V, size_t OFFSET>
+__device__ __forceinline__ V kernarg_field()
 {
+    typedef const char __attribute__((address_space(4))) *KernargBytes;
+    KernargBytes base = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));   // loaded here, every time: not hoisted into a long-lived SGPR
+    return *(const V __attribute__((address_space(4))) *)(base + OFFSET);
+}
+#define ZOIC_KARG(field) kernarg_field<decltype(RefillArgs::field), offsetof(RefillArgs, field)>()
+
+// GUARD (FAST only) = the decision-safe mode: every accept/reject decision of a try is checked against its guard band
+// (tables.hpp FastSurface::band*); a ray with a decision too close to call is dropped where it stands -- no record, no
+// counter -- and its index is appended to `redoList`.  REDO (STRICT only) = the kernel that runs next on the stream and
+// evaluates exactly the listed rays from scratch in the reference's arithmetic.  Together: every ray's try count, weight
+// and flags are the reference's; only the low-order bits of origin / direction of the FAST-evaluated rays differ.
+template <bool STRICT, int NS, bool GUARD, bool REDO>
+__device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
+                                                 uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching,
+                                                 const unsigned int *__restrict__ redoCount)
+{
+    static_assert(!(GUARD && STRICT) && !(REDO && !STRICT), "GUARD is a FAST mode, REDO a STRICT one");
+    uint32_t redoChunk = 0, redoChunksPerPart = 0;
+    // REDO waves are sparsely populated and their rays' chains are the kernel's whole duration: a lane keeps drawing while
+    // ANY lane is still looking (with the production threshold of 16 a lone ray pays a full pass per try)
+    if constexpr (REDO) minSearching = 1u;
+    if constexpr (REDO) {   // the work list's length is only known on the device
+        n = *redoCount;         // <= samples of the launch, which is what the list was sized for
+        if (n == 0u) return;
+        // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times
+        // over: a claim costs three dependent round trips (cursor, list, samples) and is amortised over the chunk
+        redoChunk = n > (1u << 20) ? 256u : 64u;
+        const uint32_t totalChunks = (n + redoChunk - 1u) / redoChunk;
+        if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed (the usual case for most of the grid)
+        redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the
     // two entries a sample interpolates -- then (ldsWords > 0) the bokeh row cell records (tables.hpp)
@@ -97,6 +137,21 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     // hides under the trace; refilled lanes fetch their sample from lane `rank` with ds_bpermute (winBase == next)
     float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t winBase = 0xffffffffu;
+    uint32_t winIdx = 0;   // REDO: the ray index of the window's sample (read through the work list)
+    // GUARD: dropped rays are staged in the wave's own LDS list (branch-free, every pass) and moved to the STRICT kernel's
+    // work list in whole batches OUTSIDE the pass loop; TIR tallies of finished rays accumulate per lane in LDS likewise.
+    // (A wave-uniform rare block with an atomic inside the pass loop makes LLVM spill ~60 more SGPRs to VGPR lanes --
+    // 320 v_readlane against 90, +12-20 % kernel time -- although it runs for one wave-pass in a hundred.)
+    uint32_t *dropLds = reinterpret_cast<uint32_t *>(zoicDynLds + kLutLdsWords + ldsWords) + kWavesPerBlock * 576u + (threadIdx.x >> 6) * kGuardLdsWords;
+    uint32_t *tirLds = dropLds + 128;
+    uint32_t dropCnt = 0;   // wave-uniform: entries staged in dropLds
+    if constexpr (GUARD) tirLds[lane] = 0u;
+    const auto fetch_window = [&](uint32_t base) {
+        const uint32_t wi = base + lane;
+        if constexpr (REDO) { winIdx = ZOIC_KARG(redoList)[wi < n ? wi : n - 1]; win = samples[winIdx]; }
+        else win = samples[wi < n ? wi : n - 1];
+        winBase = base;
+    };
 
     // per-lane ray state, alive across passes
     bool active = false, fresh = false, dead = false;
@@ -106,23 +161,27 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     uint32_t succ = 0, vign = 0, tir = 0;   // wave totals, wave-uniform (SGPRs: ballot + popcount, no per-lane counters)
     ZOIC_RT_DECL
 
+    bool done = false;
+    do {
     for (;;) {
         ZOIC_RT_MARK(4)
         // Wave priority (s_setprio; measured, same box): with the bokeh image on, waves wait half their cycles on the sampler's
         // LDS -> global chain, and letting the waves that are in their memory phases issue first gets those loads out
         // earlier (C3 +2 %); without it the launch is compute-dense and the waves inside the trace go first (C4 +3 %).
         if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(1);
+        bool unsure = false;   // GUARD: a decision of this pass lies inside its guard band -> the ray goes to the STRICT kernel
+        FastSurfaceTable fsurf = nullptr;
+        if constexpr (GUARD && (ZOIC_GUARD_PIN != 0)) fsurf = launder_table(kernarg_fast_surfaces());   // keeps the table's s_loads at their use (fast_optics.hpp)
+        else if constexpr (!STRICT) fsurf = kernarg_fast_surfaces();
+        (void)fsurf;
         // ---- refill the free lanes from the work window (ballot + prefix sum) ---------------------------------
         unsigned long long freeMask = __ballot(!active);
         while (freeMask != 0ull && !exhausted) {
             if (next >= end) {  // claim the next chunk: one atomic per chunkRays samples per wave (work_cursor.hpp)
-                if (!claim_chunk(workCursor, lane, part, partsTried, chunkRays, chunksPerPart, n, next, end)) { exhausted = true; break; }
+                const uint32_t cr = REDO ? redoChunk : ZOIC_KARG(chunkRays), cpp = REDO ? redoChunksPerPart : ZOIC_KARG(chunksPerPart);
+                if (!claim_chunk(ZOIC_KARG(workCursor), lane, part, partsTried, cr, cpp, n, next, end)) { exhausted = true; break; }
             }
-            if (winBase != next) {  // first use of a chunk: the window has to be fetched in line (once per chunk)
-                const uint32_t wi = next + lane;
-                win = samples[wi < n ? wi : n - 1];
-                winBase = next;
-            }
+            if (winBase != next) fetch_window(next);  // first use of a chunk: the window has to be fetched in line (once per chunk)
             const uint32_t avail = end - next;
             const uint32_t nfree = static_cast<uint32_t>(__popcll(freeMask));
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(freeMask >> 32),
@@ -130,8 +189,10 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             // my sample sits in lane `rank` of the window (all lanes take part in the permute)
             const float4 s = make_float4(__shfl(win.x, rank, 64), __shfl(win.y, rank, 64), __shfl(win.z, rank, 64),
                                          __shfl(win.w, rank, 64));  // (sx, sy, lensx, lensy)
+            uint32_t listedIdx = 0;
+            if constexpr (REDO) listedIdx = __shfl(winIdx, rank, 64);
             if (!active && rank < avail) {
-                idx = next + rank;   // the retry stream is seeded lazily, at the ray's first retry (most rays never need it)
+                idx = REDO ? listedIdx : next + rank;   // the retry stream is seeded lazily, at the ray's first retry (most rays never need it)
                 o0x = s.x * T.halfSensor;  // zoic.cpp:1853-1854
                 o0y = s.y * T.halfSensor;
                 u = s.z; v = s.w;
@@ -141,6 +202,8 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                     if constexpr (STRICT) dist = fabsf(sqrtf(o0x * o0x + o0y * o0y));
                     else dist = fsqrt_fast(o0x * o0x + o0y * o0y);
                     lutMiss = lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation) ? 0u : 1u;
+                    // the only discontinuity of the lookup is the table's end (bin edges interpolate continuously)
+                    if constexpr (GUARD) unsure = fabsf(dist * 8.0f - static_cast<float>(T.lutSize - 1)) < T.bandLutBin;
                     // Outside the image circle the LUT entries are all zero (zoic.cpp:1403-1404 never grown): every try
                     // then shoots lens = (0,0).  With o0x != 0 and o0y != 0 the direction (0 - o0x, 0 - o0y, dirZ) is
                     // bit-identical for all 27 tries whatever the signs of the zeros, so one failed trace decides them all.
@@ -164,7 +227,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             if (nfree <= avail) break;
             freeMask = __ballot(!active);
         }
-        if (__ballot(active) == 0ull) break;
+        if (__ballot(active) == 0ull) { done = true; break; }
         ZOIC_RT_MARK(0)
 
         // ---- one try for every active lane ---------------------------------------------------------------------
@@ -177,14 +240,15 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         // kMinSearching lanes are still looking, the rest simply carry their search into the next pass.
         V3 o{o0x, o0y, T.originShift}, d{0.0f, 0.0f, 1.0f};
         bool cand = false, finiteSample = true;
-        bool searching = active;
+        bool searching = GUARD ? (active && !unsure) : active;
         for (;;) {
             if (searching) {
                 const bool first = fresh;
                 if (!first) {                       // retry: new lens sample from the ray's own stream, zoic.cpp:1930
                     if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
-                        if (rngStates) { const uint4 r = rngStates[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
-                        else rng = rng_for_ray(T.seed, rayBase + idx);
+                        const uint4 *states = ZOIC_KARG(rngStates);
+                        if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+                        else rng = rng_for_ray(kernarg_field<uint32_t, offsetof(RefillArgs, T) + offsetof(KolbTable, seed)>(), ZOIC_KARG(rayBase) + idx);
                     }
                     u = rng_unit(xor128(rng));
                     v = rng_unit(xor128(rng));
@@ -212,13 +276,15 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                     const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
                     d = V3{rx - o.x, ry - o.y, T.dirZ};
                 }
-                bool pass0;
+                bool pass0, near0 = false;
                 if constexpr (STRICT) pass0 = interface0_clear_strict(T, o, d);
-                else pass0 = interface0_clear_fast(T.fsurf[0], o, d);
+                else if constexpr (GUARD) pass0 = interface0_clear_fast_guard(load_surface<false>(fsurf, 0), o, d, near0);   // band 0 unless the rear interface is the stop
+                else pass0 = interface0_clear_fast(load_surface<false>(fsurf, 0), o, d);
 #ifdef ZOIC_EXP_DOUBLE_PRETEST
-                if constexpr (!STRICT) { V3 d2 = d; d2.x += pass0 ? 0.0f : 1.0e-30f; pass0 = pass0 & interface0_clear_fast(T.fsurf[0], o, d2); }
+                if constexpr (!STRICT) { V3 d2 = d; d2.x += pass0 ? 0.0f : 1.0e-30f; pass0 = pass0 & interface0_clear_fast(load_surface(fsurf, 0), o, d2); }
 #endif
-                if (pass0) { cand = true; searching = false; }
+                if (GUARD && near0) { unsure = true; searching = false; }   // too close to call: no decision is taken here
+                else if (pass0) { cand = true; searching = false; }
                 else {
                     // a clip at interface 0 bumps no TIR counter and leaves (o, d) untouched: with the dead-pixel
                     // shortcut all 27 tries are this one
@@ -235,11 +301,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         // Issued here, not in the refill: vmcnt is one in-order counter, so the lens sampler's dependent global load
         // (cell record) waits for every older memory operation -- a window load issued before the search would be waited
         // for, at full HBM latency, inside the search instead of flying under the trace.
-        if (next < end && winBase != next) {
-            const uint32_t wi = next + lane;
-            win = samples[wi < n ? wi : n - 1];
-            winBase = next;
-        }
+        if (next < end && winBase != next) fetch_window(next);
         if (parked) { flush_parked_records(out, stage, stageIdx, lane); parked = false; }
         // ---- one full trace for every lane that holds a candidate -----------------------------------------------------
         bool ok = false;
@@ -250,23 +312,31 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             uint32_t tirTry = 0;   // 0/1: this try ended in total internal reflection
             if constexpr (NS > 0) {
                 if constexpr (STRICT) ok = trace_lens_strict_pred<NS>(T, o, d, tirTry, cand);
-                else ok = trace_lens_fast_pred<NS>(T.fsurf, o, d, tirTry, cand);
+                else if constexpr (GUARD) { bool u2 = false; ok = trace_lens_fast_pred<NS, true>(fsurf, o, d, tirTry, cand, &u2); unsure |= cand && u2; }
+                else ok = trace_lens_fast_pred<NS>(fsurf, o, d, tirTry, cand);
 #ifdef ZOIC_EXP_DOUBLE_TRACE
-                if constexpr (!STRICT) { V3 o2 = oStart, d2 = dStart; uint32_t t2 = 0; o2.x += o.x * 0.0f; const bool ok2 = trace_lens_fast_pred<NS>(T.fsurf, o2, d2, t2, cand); o.x += o2.x * 0.0f; ok = ok & (ok2 | !ok); }
+                if constexpr (!STRICT) { V3 o2 = oStart, d2 = dStart; uint32_t t2 = 0; o2.x += o.x * 0.0f; const bool ok2 = trace_lens_fast_pred<NS>(fsurf, o2, d2, t2, cand); o.x += o2.x * 0.0f; ok = ok & (ok2 | !ok); }
 #endif
             } else if (cand) {
                 if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
+                else if constexpr (GUARD) { bool u2 = false; ok = trace_lens_fast_rolled(T, o, d, tirTry, &u2); unsure |= u2; }
                 else ok = trace_lens_fast_rolled(T, o, d, tirTry);
             }
-            const bool shortcut = cand && !ok && firstTry && dead && finiteSample;
+            const bool shortcut = cand && !ok && firstTry && dead && finiteSample && !(GUARD && unsure);
             // the shortcut stands for 26 more identical failures: account for their TIR bumps as well
-            tir += static_cast<uint32_t>(__popcll(__ballot(tirTry != 0u))) +
-                   (static_cast<uint32_t>(kMaxTries) + 1u) * static_cast<uint32_t>(__popcll(__ballot(shortcut && tirTry != 0u)));
+            if constexpr (GUARD) {
+                // a dropped ray must leave no trace in the counters (the STRICT kernel counts it): TIR bumps are tallied per
+                // ray, above bit 0 of lutMiss, and reach the wave total only when the ray finishes here
+                if (!unsure) lutMiss += (tirTry << 1) + (shortcut ? (tirTry * (static_cast<uint32_t>(kMaxTries) + 1u)) << 1 : 0u);
+            } else {
+                tir += static_cast<uint32_t>(__popcll(__ballot(tirTry != 0u))) +
+                       (static_cast<uint32_t>(kMaxTries) + 1u) * static_cast<uint32_t>(__popcll(__ballot(shortcut && tirTry != 0u)));
+            }
             if (shortcut) tries = static_cast<uint32_t>(kMaxTries) + 1u;   // ... then finish the ray as the reference would
             if constexpr (NS > 0) {
                 // the predicated trace does not keep the partial state of a failed ray; a ray that FINISHES failed
                 // (out of tries) gets it from the branchy trace, which stops at the failing interface
-                if (cand && !ok && tries > static_cast<uint32_t>(kMaxTries)) {
+                if (cand && !ok && tries > static_cast<uint32_t>(kMaxTries) && !(GUARD && unsure)) {
                     uint32_t ignored = 0;
                     o = oStart; d = dStart;
                     if constexpr (STRICT) (void)trace_lens_strict(T, o, d, ignored);
@@ -281,7 +351,19 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         ZOIC_RT_MARK(2)
         if (!cand) { o = oStart; d = dStart; }
         uint32_t finishedIdx = 0xffffffffu;
-        const bool finished = active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries));
+        const bool finished = active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries)) && !(GUARD && unsure);
+        if constexpr (GUARD) {
+            // branch-free: stage the dropped rays' indices, add the finished rays' TIR tallies
+            const bool drop = active && unsure;
+            const uint32_t tally = finished ? (lutMiss >> 1) : 0u;
+            if (__ballot(drop || tally != 0u) != 0ull) {   // LDS traffic only: keeps the pass loop free of global atomics
+                const unsigned long long dropMask = __ballot(drop);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dropMask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dropMask), 0u));
+                if (drop) { dropLds[dropCnt + r] = idx; active = false; }
+                dropCnt += static_cast<uint32_t>(__popcll(dropMask));
+                if (tally != 0u) tirLds[lane] += tally;
+            }
+        }
         {
             const uint32_t nv = static_cast<uint32_t>(__popcll(__ballot(finished && tries > static_cast<uint32_t>(kMaxTries))));
             vign += nv;                                                                       // zoic.cpp:1951-1957
@@ -292,17 +374,36 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
             stage[2 * lane] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);                 // zoic.cpp:1960-1961
             stage[2 * lane + 1] = make_float4(d.y * -1.0f, d.z * -1.0f, w,
-                                              __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6)));
+                                              __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | ((lutMiss & 1u) << 6)));
             finishedIdx = idx;
             active = false;
         }
         stageIdx[lane] = finishedIdx;
         parked = true;
+        if constexpr (GUARD) { if (dropCnt > 64u) break; }   // the LDS list must keep room for a whole pass: flush below
     }
+    if constexpr (GUARD) {
+        // move the staged indices to the STRICT kernel's work list: one atomic reserves exactly dropCnt entries
+        if (dropCnt != 0u) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(ZOIC_KARG(redoCount), dropCnt);
+            at = __builtin_amdgcn_readfirstlane(at);
+            uint32_t *list = ZOIC_KARG(redoList);
+            for (uint32_t j = lane; j < dropCnt; j += 64u) list[at + j] = dropLds[j];
+            dropCnt = 0;
+        }
+    }
+    } while (!done);
 
     if (parked) flush_parked_records(out, stage, stageIdx, lane);   // records parked by the last pass
+    if constexpr (GUARD) {   // TIR bumps of the rays this wave finished
+        uint32_t t = tirLds[lane];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        tir += static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+    }
     ZOIC_RT_FLUSH
     // ---- counters: the wave totals, one atomic per counter per wave ---------------------------------------------
+    DeviceCounters *counters = ZOIC_KARG(counters);
     if (counters) {
         if (lane == 0) {
             if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
@@ -312,32 +413,47 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     }
 }
 
-// the two precisions are separate kernels only so that each can carry its own register-budget attributes
+// the precisions / modes are separate kernels so that each can carry its own register-budget attributes
 #define ZOIC_REFILL_PARAMS const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, \
         uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,          \
-        uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching
+        uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList,               \
+        unsigned int *__restrict__ redoCount
+#define ZOIC_REFILL_ARGS T, B, samples, n, out, ldsWords, minSearching, redoCount
 template <int NS>
 __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_STRICT void kolb_refill_strict_kernel(ZOIC_REFILL_PARAMS)
 {
-    kolb_refill_body<true, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, chunksPerPart, minSearching);
+    kolb_refill_body<true, NS, false, false>(ZOIC_REFILL_ARGS);
 }
-template <int NS>
+template <int NS>   // STRICT over the rays the decision-safe FAST kernel listed
+__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_STRICT void kolb_refill_redo_kernel(ZOIC_REFILL_PARAMS)
+{
+    kolb_refill_body<true, NS, false, true>(ZOIC_REFILL_ARGS);
+}
+template <int NS>   // FAST, decisions unchecked (round 1's fast mode; ZOIC_PRECISION_FAST_UNCHECKED)
 __global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_FAST void kolb_refill_fast_kernel(ZOIC_REFILL_PARAMS)
 {
-    kolb_refill_body<false, NS>(T, B, samples, rngStates, rayBase, n, out, counters, workCursor, ldsWords, chunkRays, chunksPerPart, minSearching);
+    kolb_refill_body<false, NS, false, false>(ZOIC_REFILL_ARGS);
+}
+template <int NS>   // FAST, decision-safe (ZOIC_PRECISION_FAST)
+__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_FAST void kolb_refill_guard_kernel(ZOIC_REFILL_PARAMS)
+{
+    kolb_refill_body<false, NS, true, false>(ZOIC_REFILL_ARGS);
 }
 #undef ZOIC_REFILL_PARAMS
+#undef ZOIC_REFILL_ARGS
 
+// mode: 0 = STRICT, 1 = FAST decision-safe (needs d_redoList: room for every sample of the launch), 2 = FAST unchecked
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                        uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                       bool fast, void *stream)
+                       int mode, uint32_t *d_redoList, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mode == 1 && !d_redoList) return static_cast<int>(hipErrorInvalidValue);
     // one launch covers < 2^31 samples (32-bit ray offsets inside the kernel); larger batches are split
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;
     for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
         const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
-        hipError_t e = reset_work_cursors(d_workCursor, st);
+        hipError_t e = reset_work_cursors(d_workCursor, st);   // both cursor sets and the work-list counter
         if (e != hipSuccess) return static_cast<int>(e);
         const unsigned grid = persistent_grid(m, kWavesPerBlock);
         const WorkGrain grain = work_grain(m);
@@ -350,33 +466,41 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
         // ZOIC_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the workgroups a CU admits
         static const size_t ldsPad = [] { const char *e = std::getenv("ZOIC_LDS_PAD"); return e ? static_cast<size_t>(std::atol(e)) : size_t(0); }();
-        const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + kWavesPerBlock * 144 * sizeof(float4) + ldsPad;
-#define ZOIC_REFILL_KERNEL_true kolb_refill_strict_kernel
-#define ZOIC_REFILL_KERNEL_false kolb_refill_fast_kernel
-#define ZOIC_LAUNCH_REFILL(STRICT_, NS_)                                                                                       \
-    hipLaunchKernelGGL((ZOIC_REFILL_KERNEL_##STRICT_<NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp,  \
-                       rayBase + done, static_cast<uint32_t>(m), o, d_counters, d_workCursor, ldsWords, chunkRays, chunksPerPart, minSearching)
-        if (!fast) switch (table.lensCount) {
-            case 7: ZOIC_LAUNCH_REFILL(true, 7); break;
-            case 8: ZOIC_LAUNCH_REFILL(true, 8); break;
-            case 9: ZOIC_LAUNCH_REFILL(true, 9); break;
-            case 10: ZOIC_LAUNCH_REFILL(true, 10); break;
-            case 11: ZOIC_LAUNCH_REFILL(true, 11); break;
-            case 12: ZOIC_LAUNCH_REFILL(true, 12); break;
-            default: ZOIC_LAUNCH_REFILL(true, 0); break;
+        const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + kWavesPerBlock * 144 * sizeof(float4) + ldsPad +
+                                (mode == 1 ? kWavesPerBlock * kGuardLdsWords * sizeof(uint32_t) : 0);
+        unsigned int *redoCount = d_workCursor + kRedoCountOffset;
+        unsigned int *redoCursor = d_workCursor + kRedoCursorOffset;
+#define ZOIC_LAUNCH_REFILL(KERNEL_, NS_, CURSOR_, GRID_)                                                                        \
+    hipLaunchKernelGGL((KERNEL_<NS_>), dim3(GRID_), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp, rayBase + done,      \
+                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, minSearching, d_redoList, redoCount)
+#define ZOIC_LAUNCH_BY_COUNT(KERNEL_, CURSOR_, GRID_)                                                                           \
+    switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                   \
+    case 7: ZOIC_LAUNCH_REFILL(KERNEL_, 7, CURSOR_, GRID_); break;                                                              \
+    case 8: ZOIC_LAUNCH_REFILL(KERNEL_, 8, CURSOR_, GRID_); break;                                                              \
+    case 9: ZOIC_LAUNCH_REFILL(KERNEL_, 9, CURSOR_, GRID_); break;                                                              \
+    case 10: ZOIC_LAUNCH_REFILL(KERNEL_, 10, CURSOR_, GRID_); break;                                                            \
+    case 11: ZOIC_LAUNCH_REFILL(KERNEL_, 11, CURSOR_, GRID_); break;                                                            \
+    case 12: ZOIC_LAUNCH_REFILL(KERNEL_, 12, CURSOR_, GRID_); break;                                                            \
+    default: ZOIC_LAUNCH_REFILL(KERNEL_, 0, CURSOR_, GRID_); break;                                                             \
+    }
+        if (mode == 0) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_kernel, d_workCursor, grid) }
+        else if (mode == 2) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_kernel, d_workCursor, grid) }
+        else {
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_kernel, d_workCursor, grid)
+            e = hipGetLastError();
+            if (e != hipSuccess) return static_cast<int>(e);
+            // the rays it listed, in the reference's arithmetic; workgroups beyond the list's length retire at once
+            static const bool dbg = std::getenv("ZOIC_DEBUG_REDO") != nullptr;   // experiments: how long is the work list?
+            if (dbg) {
+                unsigned int c = 0;
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(&c, redoCount, sizeof(c), hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "[zoic] decision-safe fast: %u of %llu rays handed to the strict kernel (%.3g)\n", c, static_cast<unsigned long long>(m), double(c) / double(m));
+            }
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_redo_kernel, redoCursor, grid)
         }
-        else switch (table.lensCount) {  // unrolled instantiations for the interface counts of real prescriptions
-            case 7: ZOIC_LAUNCH_REFILL(false, 7); break;
-            case 8: ZOIC_LAUNCH_REFILL(false, 8); break;
-            case 9: ZOIC_LAUNCH_REFILL(false, 9); break;
-            case 10: ZOIC_LAUNCH_REFILL(false, 10); break;
-            case 11: ZOIC_LAUNCH_REFILL(false, 11); break;
-            case 12: ZOIC_LAUNCH_REFILL(false, 12); break;
-            default: ZOIC_LAUNCH_REFILL(false, 0); break;
-        }
+#undef ZOIC_LAUNCH_BY_COUNT
 #undef ZOIC_LAUNCH_REFILL
-#undef ZOIC_REFILL_KERNEL_true
-#undef ZOIC_REFILL_KERNEL_false
         e = hipGetLastError();
         if (e != hipSuccess) return static_cast<int>(e);
     }

@@ -222,6 +222,18 @@ void LensSystem::fill_surfaces(KolbTable &t) const
     t.originShift = originShift;
     t.dirZ = -rows[0].thickness;
     t.rearAperture = rows[0].aperture;
+    // Guard bands of the decision-safe FAST mode.  FAST and STRICT evaluate the same formulas with different roundings
+    // (FMA, rsq/sqrt approximations, folded constants), so they can only disagree where the reference's own f32 rounding
+    // noise decides.  That noise is large at ONE kind of interface: the stop, which the reference traces as a sphere of
+    // |R| ~ 10^4 cm (radius 0 -> 99999 mm, zoic.cpp:933).  There t = tca - thc cancels two numbers of magnitude |R|, the hit
+    // point is only good to ~ulp(|R|) ~ 1e-3 cm, and the clip h^2 > r_stop^2 is decided by rounding for rays within
+    // eps*|R|/r_stop (1e-4 ... 5e-3, relative) of the edge.  Measured (tools/flip_analysis.py, 8.4 M rays per config): every
+    // FAST/STRICT disagreement but ~1e-7 of the rays is decided at the stop, with relative margins up to 0.9 x eps*|R|/r_stop.
+    // An interface is guarded when that estimate exceeds kGuardMinRelBand (well-conditioned interfaces sit at ~1e-6 and
+    // disagree on < 1e-6 of the rays); its band is kGuardScale times the estimate.  ZOIC_GUARD_SCALE overrides (experiments).
+    static const float guardScale = [] { const char *e = std::getenv("ZOIC_GUARD_SCALE"); return e ? static_cast<float>(std::atof(e)) : kGuardScale; }();
+    const float eps = 5.9604645e-8f;
+    t.bandLutBin = 16.0f * eps * 32.0f;   // dist*8 <= 31: a few ulps of the bin coordinate
     for (int i = 0; i < n; ++i) {
         Surface &s = t.surf[i];
         const LensRow &r = rows[i];
@@ -250,6 +262,8 @@ void LensSystem::fill_surfaces(KolbTable &t) const
         q.etaInvAbsR = static_cast<float>(eta * std::fabs(invR));
         q.e2InvR2 = static_cast<float>(eta * eta * invR * invR);
         q.oneMinusEta2 = static_cast<float>(1.0 - eta * eta);
+        const float relBand = eps * std::fabs(r.radius) / std::sqrt(s.housing2);   // relative to housing2
+        q.bandHousing = (relBand > kGuardMinRelBand) ? guardScale * relBand * s.housing2 : 0.0f;
     }
 }
 

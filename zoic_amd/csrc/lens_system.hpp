@@ -26,6 +26,11 @@ struct LensRow {
     float radius = 0, thickness = 0, ior = 0, aperture = 0, abbe = 0, center = 0;
 };
 
+// decision-safe FAST mode (lens_system.cpp fill_surfaces): interfaces whose rounding-noise estimate eps*|R|/sqrt(housing2)
+// exceeds kGuardMinRelBand are guarded with a band of kGuardScale x the estimate
+constexpr float kGuardScale = 2.0f;
+constexpr float kGuardMinRelBand = 2.0e-5f;
+
 struct LutBox { float maxX = 0, maxY = 0, minX = 0, minY = 0; };  // boundingBox2d, zoic.cpp:490-493
 
 // Accept/reject of one batch of exit-pupil probe rays.  The default implementation traces on the host;

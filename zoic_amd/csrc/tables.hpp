@@ -48,7 +48,11 @@ struct FastSurface {
     float etaInvAbsR;    // eta/|R|          : eta*cos(i) = thc * etaInvAbsR
     float e2InvR2;       // eta^2/R^2        : 1 - cs2 = oneMinusEta2 + e2InvR2 * thc^2
     float oneMinusEta2;  // 1 - eta^2
-    float pad0, pad1, pad2;
+    // Guard bands of the decision-safe FAST mode (kolb_refill.hip): a FAST decision is trusted only when its operands are
+    // further from the decision boundary than the band; otherwise the ray is handed to the STRICT kernel.
+    float bandHousing;   // > 0 on guarded (ill-conditioned) interfaces only: |h^2 - housing2| < bandHousing means the
+                         // housing / stop clip (zoic.cpp:1111-1117) is too close to call in FAST arithmetic; 0: not guarded
+    float pad0, pad1;
 };
 
 struct KolbTable {
@@ -66,7 +70,7 @@ struct KolbTable {
     float exposureMul;    // 1+e^2, 1/(1+e^2) or 1 (zoic.cpp:1981-1987)
     int32_t exposureOn;
     uint32_t seed;
-    int32_t pad0;
+    float bandLutBin;     // decision-safe FAST: |dist*8 - round(dist*8)| below this leaves the LUT bin to STRICT
     Surface surf[kMaxSurfaces];
     FastSurface fsurf[kMaxSurfaces];
     float lutMaxScale[kLutEntries];  // boundingBox2d::getMaxScale per LUT entry (zoic.cpp:503-517)
