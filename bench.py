@@ -45,7 +45,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
-    ap.add_argument("--precision", default=os.environ.get("ZOIC_BENCH_PRECISION", "fast"), choices=["fast", "strict"])
+    ap.add_argument("--precision", default=os.environ.get("ZOIC_BENCH_PRECISION", "fast"), choices=["fast", "unchecked", "strict"],
+                    help="fast = ZOIC_PRECISION_FAST (decision-safe), unchecked = ZOIC_PRECISION_FAST_UNCHECKED (round 1's fast), strict = bit-exact")
     ap.add_argument("--rays", type=int, default=0, help="override the per-GPU sample count of the headline workload (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -60,13 +61,13 @@ def parse_args():
 
 # ------------------------------------------------------------------------------------------------- cameras
 def make_camera(cfg_name, precision, device):
-    from zoic_amd import PRECISION_FAST, PRECISION_STRICT, ZoicCamera
+    from zoic_amd import PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, ZoicCamera
     from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh
     cam = ZoicCamera(device=device)
     if CONFIGS[cfg_name]["bokeh"]:
         cam.set_bokeh_image(hexagon_bokeh())
     cam.update(**camera_params(cfg_name))
-    cam.set_precision(PRECISION_FAST if precision == "fast" else PRECISION_STRICT)
+    cam.set_precision({"fast": PRECISION_FAST, "unchecked": PRECISION_FAST_UNCHECKED, "strict": PRECISION_STRICT}[precision])
     return cam
 
 
@@ -163,7 +164,8 @@ def pmc_entry(cfg_name, precision):
 def roofline_block(cfg_name, precision, n, kernel_ms, thin):
     achieved = ALGO_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9
     ent = pmc_entry(cfg_name, precision)
-    kernel = "thin_rays_kernel" if thin else "kolb_refill_%s_kernel" % precision
+    kernel = "thin_rays_kernel" if thin else {"fast": "kolb_refill_guard_kernel (+ heavy-list and strict redo kernels of the launch)",
+                                              "unchecked": "kolb_refill_fast_kernel", "strict": "kolb_refill_strict_kernel"}[precision]
     roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": ent.get("hbm_bytes_per_launch") if ent else None,
@@ -377,7 +379,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.config, cfg["desc"]), "rays_per_gpu_per_step": n,
-                       "precision_mode": args.precision,
+                       "precision_mode": args.precision + (" (decision-safe: try counts, weights, flags and counters are the reference's)" if args.precision == "fast" else ""),
                        "parallelism": "independent frames per GPU (dp%d), no data-path collective" % world},
             "roofline": roof,
             "zero_weight_frac": round(counters["vignettedRays"] / max(done, 1), 5),

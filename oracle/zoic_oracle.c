@@ -33,6 +33,19 @@
  *   AI_PI = 3.14159265358979323846f, AI_PIOVER2 = 1.57079632679489661923f, AI_P2_ZERO=(0,0)
  * Call sites: zoic.cpp:974,977,979,1002,1009-1010,1015,1046-1048,1777,1800,1810,1816.
  *
+ * TWO ASSUMPTIONS NO REFERENCE-HELD VECTOR CAN PIN (stated here so that nobody mistakes them for facts):
+ *  (i)  ARGUMENT EVALUATION ORDER.  The reference draws a retry's two random numbers inside ONE argument list --
+ *       `concentricDiskSample(xor128() / 4294967296.0, xor128() / 4294967296.0, &lens)` (zoic.cpp:1806, 1881, 1930;
+ *       likewise bokehSample at 1808, 1883, 1932).  C++ leaves the order of the two xor128() calls unsequenced.  This
+ *       restatement takes LEFT TO RIGHT (first draw -> first parameter), which is what clang does and clang++ is the
+ *       compiler the reference's Makefile names (reference Makefile:6).  g++ evaluates right to left and would swap u and v
+ *       of every retry: a g++ build of the reference is a different (equally valid) sample sequence, not a bug here.
+ *  (ii) THE ARNOLD INLINES listed above.  The SDK headers are not in the tree; the formulas are the published Arnold 5
+ *       ones and the draw.zoic replay agrees with them to float rounding, but their exact operation order (e.g. whether
+ *       AiV3Normalize multiplies by a reciprocal or divides) is pinned only to that level.
+ * tests/test_oracle_properties.py holds property pins for the functions without reference vectors, so that an edit of this
+ * file cannot drift silently.
+ *
  * FP DISCIPLINE: strict IEEE binary32 with the reference's scattered binary64
  * intermediates (unsuffixed literals) mirrored one by one.
  * Build with -ffp-contract=off, no fast-math.  `atan2(float,float)` at

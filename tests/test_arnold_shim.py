@@ -1,0 +1,33 @@
+"""arnold/zoic_amd_node.cpp: no Arnold SDK exists in this image, so what can be checked here is that the
+guarded translation unit compiles and links against libzoic_amd.so, and that every C-ABI call the shim makes is one the
+header declares.  The SDK-side macros are unverified until the file meets a real SDK (said so in the file)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shim_stub_builds_without_the_sdk(tmp_path):
+    out = tmp_path / "zoic_amd_stub.so"
+    subprocess.check_call(["g++", "-std=c++11", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "arnold", "zoic_amd_node.cpp"), "-o", str(out)])
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", str(out)], text=True)
+    assert "zoic_amd_arnold_shim_status" in syms
+
+
+def test_shim_calls_only_declared_entry_points():
+    src = open(os.path.join(ROOT, "arnold", "zoic_amd_node.cpp")).read()
+    src = re.sub(r"//.*", "", src)
+    hdr = open(os.path.join(ROOT, "include", "zoic_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(zoic_[a-z0-9_]+)\s*\(", hdr))
+    used = set(re.findall(r"\b(zoic_[a-z0-9_]+)\s*\(", src)) - {"zoic_amd_arnold_shim_status"}
+    assert used and used <= declared, used - declared
+    # the five node methods + reverse ray + loader of the reference's method table are all mapped
+    for method in ("node_parameters", "node_initialize", "node_update", "node_finish", "camera_create_ray", "camera_reverse_ray", "node_loader"):
+        assert re.search(r"^%s\b" % method, src, flags=re.M), method
+    # the 14 parameter names of zoic.cpp:1547-1562
+    for name in ("sensorWidth", "sensorHeight", "focalLength", "fStop", "focalDistance", "useImage", "bokehPath", "lensModel",
+                 "lensDataPath", "kolbSamplingLUT", "useDof", "opticalVignettingDistance", "opticalVignettingRadius", "exposureControl"):
+        assert '"%s"' % name in src, name

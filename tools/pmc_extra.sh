@@ -6,7 +6,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=gpurun_out/pmcx_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity $*"
+BENCH="python bench.py --steps 3 --warmup 1 --only-headline $*"
 i=0
 for grp in "SQ_INST_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_BRANCH SQ_IFETCH SQ_IFETCH_LEVEL SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_WAVE_CYCLES" \
            "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_INST_CYCLES_SMEM" \

@@ -1,25 +1,33 @@
-"""Summarise a tools/profile.sh output directory: kernel stats + PMC-derived rates for the dominant kernel."""
+"""Summarise a tools/profile.sh output directory: kernel stats + PMC-derived rates of one camera_create_ray launch.
+A Kolb launch is a short pipeline of kernels (kolb_refill.hip: main kernel, heavy-list kernel, STRICT redo kernel): counters
+are averaged per dispatch for every kernel of the pipeline and then SUMMED over the pipeline, so every figure is per launch."""
 import collections, csv, glob, json, sys
 base, nrays = sys.argv[1], float(sys.argv[2])
 pat = sys.argv[3] if len(sys.argv) > 3 else "kolb"
 st = glob.glob(base + "/trace/*/*_kernel_stats.csv")
+launch_us = 0.0
 if st:
-    for r in list(csv.DictReader(open(st[0])))[:3]:
-        print("%-60s calls %s avg_us %.1f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+    for r in list(csv.DictReader(open(st[0]))):
+        if pat in r["Name"]:
+            print("%-66s calls %s avg_us %.1f" % (r["Name"][:66], r["Calls"], float(r["AverageNs"]) / 1e3))
+            launch_us += float(r["AverageNs"]) / 1e3
+    print("pipeline per launch: %.1f us" % launch_us)
 tot = {}
 for d in sorted(glob.glob(base + "/pmc*/*/*_counter_collection.csv")):
-    acc = collections.defaultdict(list)
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))     # counter -> kernel -> values
     for r in csv.DictReader(open(d)):
         if pat in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            tot["_vgpr"], tot["_sgpr"], tot["_lds"] = r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size")
-    for k, v in acc.items():
-        tot[k] = sum(v) / len(v)
+            acc[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            if "listed" not in r["Kernel_Name"]:
+                tot["_vgpr"], tot["_sgpr"], tot["_lds"] = r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size")
+    for k, per_kernel in acc.items():
+        tot[k] = sum(sum(v) / len(v) for v in per_kernel.values())
 g = lambda k: tot.get(k, float("nan"))
 cyc = g("GRBM_GUI_ACTIVE") / 8
 simd = cyc * 1024
 out = {
-    "vgpr/sgpr/lds": (tot.get("_vgpr"), tot.get("_sgpr"), tot.get("_lds")),
+    "pipeline_us_per_launch": launch_us,
+    "vgpr/sgpr/lds (main kernel)": (tot.get("_vgpr"), tot.get("_sgpr"), tot.get("_lds")),
     "lane_instr_per_ray": g("SQ_INSTS_VALU") * 64 / nrays,
     "valu_thread_util": g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64),
     "salu_per_valu": g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"),

@@ -52,10 +52,17 @@ namespace zoic {
 // pass loop, summed over all waves.  Not part of the product build.
 #ifdef ZOIC_REGION_TIMERS
 __device__ unsigned long long g_regionCycles[8];
+__device__ unsigned long long g_passStats[8];   // passes, sum active lanes, search iterations, sum looking lanes, trace passes, sum cand lanes, rays finished
+#define ZOIC_PS_DECL unsigned long long ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ZOIC_PS_ADD(I, V) ps[I] += (V);
+#define ZOIC_PS_FLUSH if (lane == 0) { for (int r = 0; r < 8; ++r) atomicAdd(&g_passStats[r], ps[r]); }
 #define ZOIC_RT_DECL unsigned long long rtAcc[5] = {0, 0, 0, 0, 0}, rtLast = __builtin_readcyclecounter();
 #define ZOIC_RT_MARK(R) { const unsigned long long rtNow = __builtin_readcyclecounter(); rtAcc[R] += rtNow - rtLast; rtLast = rtNow; }
 #define ZOIC_RT_FLUSH if (lane == 0) { for (int r = 0; r < 5; ++r) atomicAdd(&g_regionCycles[r], rtAcc[r]); atomicAdd(&g_regionCycles[7], 1ull); }
 #else
+#define ZOIC_PS_DECL
+#define ZOIC_PS_ADD(I, V)
+#define ZOIC_PS_FLUSH
 #define ZOIC_RT_DECL
 #define ZOIC_RT_MARK(R)
 #define ZOIC_RT_FLUSH
@@ -68,8 +75,11 @@ __device__ unsigned long long g_regionCycles[8];
 // code object's metadata, tools/isa_mix.py).
 struct RefillArgs {
     KolbTable T; BokehTables B; const float4 *samples; const uint4 *rngStates; uint64_t rayBase; uint32_t n; RayRecord *out;
-    DeviceCounters *counters; unsigned int *workCursor; uint32_t ldsWords, chunkRays, chunksPerPart, minSearching; uint32_t *redoList;
-    unsigned int *redoCount;
+    DeviceCounters *counters; unsigned int *workCursor; uint32_t ldsWords, chunkRays, chunksPerPart, minSearching;
+    const uint32_t *srcList; const unsigned int *srcCount;   // LISTED kernels: the ray indices to evaluate
+    uint32_t *heavyList; unsigned int *heavyCount;           // DROPH kernels: rays handed to the search-heavy kernel
+    uint32_t *redoList; unsigned int *redoCount;             // GUARD kernels: rays handed to the STRICT kernel
+    uint32_t heavyTries;                                     // DROPH kernels: draws without a candidate that make a ray search-heavy
 };
 template <class V, size_t OFFSET>
 __device__ __forceinline__ V kernarg_field()
@@ -81,23 +91,35 @@ __device__ __forceinline__ V kernarg_field()
 }
 #define ZOIC_KARG(field) kernarg_field<decltype(RefillArgs::field), offsetof(RefillArgs, field)>()
 
-// GUARD (FAST only) = the decision-safe mode: every accept/reject decision of a try is checked against its guard band
-// (tables.hpp FastSurface::band*); a ray with a decision too close to call is dropped where it stands -- no record, no
-// counter -- and its index is appended to `redoList`.  REDO (STRICT only) = the kernel that runs next on the stream and
-// evaluates exactly the listed rays from scratch in the reference's arithmetic.  Together: every ray's try count, weight
-// and flags are the reference's; only the low-order bits of origin / direction of the FAST-evaluated rays differ.
-template <bool STRICT, int NS, bool GUARD, bool REDO>
+// One body, six kernels.  A launch is a short pipeline of persistent kernels on the caller's stream; rays move between them
+// through compact work lists of ray indices (a dropped ray leaves no record and no counter behind and is evaluated from
+// scratch by the kernel that picks it up -- per-ray retry streams make that the same ray):
+//   main kernel (STRICT | FAST | FAST+GUARD, DROPH): the whole batch.  Drops (a) "search-heavy" rays -- still without a
+//       candidate after kHeavyTries draws: in practice pixels whose exit pupil is (almost) fully vignetted, 26 cheap draws
+//       each -- to heavyList; (b) GUARD only: rays with an accept/reject decision too close to call to redoList.
+//   heavy kernel (same arithmetic, LISTED over heavyList): every lane is a searcher, the draw loop runs at full lane
+//       utilisation (minSearching 1) instead of 12 searchers riding along 50 tracers pass after pass (C2: 55 % lane
+//       utilisation in round 1).  GUARD: may add to redoList.
+//   redo kernel (STRICT, LISTED over redoList; decision-safe FAST mode only): the reference's arithmetic for the rays whose
+//       stop clip FAST could not call (tables.hpp FastSurface::bandHousing).  Together: every ray's try count, weight and
+//       flags are the reference's; only the low-order bits of origin / direction of the FAST-evaluated rays differ.
+// Drops are staged in the wave's own LDS list, branch-free, every pass, and moved to the global lists in whole batches
+// OUTSIDE the pass loop (a wave-uniform rare block with an atomic inside the pass loop makes LLVM spill ~60 more SGPRs to
+// VGPR lanes: 320 v_readlane against 90, +12-20 % kernel time).  TIR bumps are tallied per ray (above bit 0 of lutMiss) and
+// reach the counters only when the ray finishes in this kernel.
+constexpr uint32_t kHeavyTries = 1000;     // draws without a candidate after which a ray counts as search-heavy; 1000 = never (measured: the split loses); ZOIC_HEAVY_TRIES overrides
+constexpr uint32_t kHeavySearching = 40;   // heavy kernel: the draw loop spins while at least this many lanes are looking
+constexpr uint32_t kHeavyTag = 0x80000000u;  // staged entry: heavy (else: to the STRICT kernel); ray indices are < 2^31
+
+template <bool STRICT, int NS, bool GUARD, bool LISTED, bool DROPH>
 __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
-                                                 uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching,
-                                                 const unsigned int *__restrict__ redoCount)
+                                                 uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching)
 {
-    static_assert(!(GUARD && STRICT) && !(REDO && !STRICT), "GUARD is a FAST mode, REDO a STRICT one");
+    static_assert(!(GUARD && STRICT) && !(LISTED && DROPH), "GUARD is a FAST mode; only main kernels drop search-heavy rays");
+    constexpr bool DEFER = GUARD || DROPH;   // this kernel may hand rays on
     uint32_t redoChunk = 0, redoChunksPerPart = 0;
-    // REDO waves are sparsely populated and their rays' chains are the kernel's whole duration: a lane keeps drawing while
-    // ANY lane is still looking (with the production threshold of 16 a lone ray pays a full pass per try)
-    if constexpr (REDO) minSearching = 1u;
-    if constexpr (REDO) {   // the work list's length is only known on the device
-        n = *redoCount;         // <= samples of the launch, which is what the list was sized for
+    if constexpr (LISTED) {   // the work list's length is only known on the device
+        n = *ZOIC_KARG(srcCount);   // <= samples of the launch, which is what the list was sized for
         if (n == 0u) return;
         // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times
         // over: a claim costs three dependent round trips (cursor, list, samples) and is amortised over the chunk
@@ -137,18 +159,15 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     // hides under the trace; refilled lanes fetch their sample from lane `rank` with ds_bpermute (winBase == next)
     float4 win = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t winBase = 0xffffffffu;
-    uint32_t winIdx = 0;   // REDO: the ray index of the window's sample (read through the work list)
-    // GUARD: dropped rays are staged in the wave's own LDS list (branch-free, every pass) and moved to the STRICT kernel's
-    // work list in whole batches OUTSIDE the pass loop; TIR tallies of finished rays accumulate per lane in LDS likewise.
-    // (A wave-uniform rare block with an atomic inside the pass loop makes LLVM spill ~60 more SGPRs to VGPR lanes --
-    // 320 v_readlane against 90, +12-20 % kernel time -- although it runs for one wave-pass in a hundred.)
+    uint32_t winIdx = 0;   // LISTED: the ray index of the window's sample (read through the work list)
+    // DEFER: the wave's LDS list of dropped rays (128 entries, tagged) + 64 per-lane TIR tallies of the rays it finished
     uint32_t *dropLds = reinterpret_cast<uint32_t *>(zoicDynLds + kLutLdsWords + ldsWords) + kWavesPerBlock * 576u + (threadIdx.x >> 6) * kGuardLdsWords;
     uint32_t *tirLds = dropLds + 128;
     uint32_t dropCnt = 0;   // wave-uniform: entries staged in dropLds
-    if constexpr (GUARD) tirLds[lane] = 0u;
+    if constexpr (DEFER) tirLds[lane] = 0u;
     const auto fetch_window = [&](uint32_t base) {
         const uint32_t wi = base + lane;
-        if constexpr (REDO) { winIdx = ZOIC_KARG(redoList)[wi < n ? wi : n - 1]; win = samples[winIdx]; }
+        if constexpr (LISTED) { winIdx = ZOIC_KARG(srcList)[wi < n ? wi : n - 1]; win = samples[winIdx]; }
         else win = samples[wi < n ? wi : n - 1];
         winBase = base;
     };
@@ -160,6 +179,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     Rng rng{1, 2, 3, 4};
     uint32_t succ = 0, vign = 0, tir = 0;   // wave totals, wave-uniform (SGPRs: ballot + popcount, no per-lane counters)
     ZOIC_RT_DECL
+    ZOIC_PS_DECL
 
     bool done = false;
     do {
@@ -178,7 +198,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         unsigned long long freeMask = __ballot(!active);
         while (freeMask != 0ull && !exhausted) {
             if (next >= end) {  // claim the next chunk: one atomic per chunkRays samples per wave (work_cursor.hpp)
-                const uint32_t cr = REDO ? redoChunk : ZOIC_KARG(chunkRays), cpp = REDO ? redoChunksPerPart : ZOIC_KARG(chunksPerPart);
+                const uint32_t cr = LISTED ? redoChunk : ZOIC_KARG(chunkRays), cpp = LISTED ? redoChunksPerPart : ZOIC_KARG(chunksPerPart);
                 if (!claim_chunk(ZOIC_KARG(workCursor), lane, part, partsTried, cr, cpp, n, next, end)) { exhausted = true; break; }
             }
             if (winBase != next) fetch_window(next);  // first use of a chunk: the window has to be fetched in line (once per chunk)
@@ -190,9 +210,9 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             const float4 s = make_float4(__shfl(win.x, rank, 64), __shfl(win.y, rank, 64), __shfl(win.z, rank, 64),
                                          __shfl(win.w, rank, 64));  // (sx, sy, lensx, lensy)
             uint32_t listedIdx = 0;
-            if constexpr (REDO) listedIdx = __shfl(winIdx, rank, 64);
+            if constexpr (LISTED) listedIdx = __shfl(winIdx, rank, 64);
             if (!active && rank < avail) {
-                idx = REDO ? listedIdx : next + rank;   // the retry stream is seeded lazily, at the ray's first retry (most rays never need it)
+                idx = LISTED ? listedIdx : next + rank;   // the retry stream is seeded lazily, at the ray's first retry (most rays never need it)
                 o0x = s.x * T.halfSensor;  // zoic.cpp:1853-1854
                 o0y = s.y * T.halfSensor;
                 u = s.z; v = s.w;
@@ -229,6 +249,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         }
         if (__ballot(active) == 0ull) { done = true; break; }
         ZOIC_RT_MARK(0)
+        ZOIC_PS_ADD(0, 1) ZOIC_PS_ADD(1, __popcll(__ballot(active)))
 
         // ---- one try for every active lane ---------------------------------------------------------------------
         // ---- candidate search: draw lens samples until one clears the rear element's housing -----------------------
@@ -292,8 +313,11 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                     if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
                 }
             }
+            // the loop spins while enough lanes are looking to be worth the others' wait; once the wave can no longer be
+            // refilled nobody waits for anything else, and it spins while ANY lane is looking
             const uint32_t looking = static_cast<uint32_t>(__popcll(__ballot(searching)));
-            if (looking < minSearching) break;
+            ZOIC_PS_ADD(2, 1) ZOIC_PS_ADD(3, looking)
+            if (looking < (exhausted ? 1u : minSearching)) break;
         }
 
         ZOIC_RT_MARK(1)
@@ -308,6 +332,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         const V3 oStart = o, dStart = d;
         const bool firstTry = tries == 0;
         if (__ballot(cand) != 0ull) {
+            ZOIC_PS_ADD(4, 1) ZOIC_PS_ADD(5, __popcll(__ballot(cand)))
             if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
             uint32_t tirTry = 0;   // 0/1: this try ended in total internal reflection
             if constexpr (NS > 0) {
@@ -324,9 +349,9 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             }
             const bool shortcut = cand && !ok && firstTry && dead && finiteSample && !(GUARD && unsure);
             // the shortcut stands for 26 more identical failures: account for their TIR bumps as well
-            if constexpr (GUARD) {
-                // a dropped ray must leave no trace in the counters (the STRICT kernel counts it): TIR bumps are tallied per
-                // ray, above bit 0 of lutMiss, and reach the wave total only when the ray finishes here
+            if constexpr (DEFER) {
+                // a dropped ray must leave no trace in the counters (the kernel that picks it up counts it): TIR bumps are
+                // tallied per ray, above bit 0 of lutMiss, and reach the wave total only when the ray finishes here
                 if (!unsure) lutMiss += (tirTry << 1) + (shortcut ? (tirTry * (static_cast<uint32_t>(kMaxTries) + 1u)) << 1 : 0u);
             } else {
                 tir += static_cast<uint32_t>(__popcll(__ballot(tirTry != 0u))) +
@@ -352,14 +377,16 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         if (!cand) { o = oStart; d = dStart; }
         uint32_t finishedIdx = 0xffffffffu;
         const bool finished = active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries)) && !(GUARD && unsure);
-        if constexpr (GUARD) {
-            // branch-free: stage the dropped rays' indices, add the finished rays' TIR tallies
-            const bool drop = active && unsure;
+        if constexpr (DEFER) {
+            // stage the dropped rays' indices, add the finished rays' TIR tallies (LDS traffic only)
+            const bool dropU = GUARD && active && unsure;
+            const bool dropH = DROPH && active && searching && !unsure && tries >= ZOIC_KARG(heavyTries);   // still no candidate: search-heavy
+            const bool drop = dropU || dropH;
             const uint32_t tally = finished ? (lutMiss >> 1) : 0u;
-            if (__ballot(drop || tally != 0u) != 0ull) {   // LDS traffic only: keeps the pass loop free of global atomics
+            if (__ballot(drop || tally != 0u) != 0ull) {
                 const unsigned long long dropMask = __ballot(drop);
                 const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dropMask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dropMask), 0u));
-                if (drop) { dropLds[dropCnt + r] = idx; active = false; }
+                if (drop) { dropLds[dropCnt + r] = idx | (dropU ? 0u : kHeavyTag); active = false; }
                 dropCnt += static_cast<uint32_t>(__popcll(dropMask));
                 if (tally != 0u) tirLds[lane] += tally;
             }
@@ -380,28 +407,49 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         }
         stageIdx[lane] = finishedIdx;
         parked = true;
-        if constexpr (GUARD) { if (dropCnt > 64u) break; }   // the LDS list must keep room for a whole pass: flush below
+        if constexpr (DEFER) { if (dropCnt > 64u) break; }   // the LDS list must keep room for a whole pass: flush below
     }
-    if constexpr (GUARD) {
-        // move the staged indices to the STRICT kernel's work list: one atomic reserves exactly dropCnt entries
+    if constexpr (DEFER) {
+        // move the staged indices to the global work lists: per list ONE atomic reserves exactly the entries written
         if (dropCnt != 0u) {
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(ZOIC_KARG(redoCount), dropCnt);
-            at = __builtin_amdgcn_readfirstlane(at);
-            uint32_t *list = ZOIC_KARG(redoList);
-            for (uint32_t j = lane; j < dropCnt; j += 64u) list[at + j] = dropLds[j];
+            for (uint32_t base = 0; base < dropCnt; base += 64u) {
+                const uint32_t j = base + lane;
+                const uint32_t e = j < dropCnt ? dropLds[j] : 0u;
+                const bool heavy = j < dropCnt && (e & kHeavyTag) != 0u, unsureRay = j < dropCnt && (e & kHeavyTag) == 0u;
+                if constexpr (DROPH) {
+                    const unsigned long long m = __ballot(heavy);
+                    if (m != 0ull) {
+                        uint32_t at = 0;
+                        if (lane == 0) at = atomicAdd(ZOIC_KARG(heavyCount), static_cast<unsigned int>(__popcll(m)));
+                        at = __builtin_amdgcn_readfirstlane(at);
+                        const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                        if (heavy) ZOIC_KARG(heavyList)[at + r] = e & ~kHeavyTag;
+                    }
+                }
+                if constexpr (GUARD) {
+                    const unsigned long long m = __ballot(unsureRay);
+                    if (m != 0ull) {
+                        uint32_t at = 0;
+                        if (lane == 0) at = atomicAdd(ZOIC_KARG(redoCount), static_cast<unsigned int>(__popcll(m)));
+                        at = __builtin_amdgcn_readfirstlane(at);
+                        const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                        if (unsureRay) ZOIC_KARG(redoList)[at + r] = e;
+                    }
+                }
+            }
             dropCnt = 0;
         }
     }
     } while (!done);
 
     if (parked) flush_parked_records(out, stage, stageIdx, lane);   // records parked by the last pass
-    if constexpr (GUARD) {   // TIR bumps of the rays this wave finished
+    if constexpr (DEFER) {   // TIR bumps of the rays this wave finished
         uint32_t t = tirLds[lane];
         for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
         tir += static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
     }
     ZOIC_RT_FLUSH
+    ZOIC_PS_FLUSH
     // ---- counters: the wave totals, one atomic per counter per wave ---------------------------------------------
     DeviceCounters *counters = ZOIC_KARG(counters);
     if (counters) {
@@ -413,53 +461,52 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     }
 }
 
-// the precisions / modes are separate kernels so that each can carry its own register-budget attributes
+// the precisions / roles are separate kernels so that each can carry its own register-budget attributes
 #define ZOIC_REFILL_PARAMS const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, \
         uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,          \
-        uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList,               \
-        unsigned int *__restrict__ redoCount
-#define ZOIC_REFILL_ARGS T, B, samples, n, out, ldsWords, minSearching, redoCount
-template <int NS>
-__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_STRICT void kolb_refill_strict_kernel(ZOIC_REFILL_PARAMS)
-{
-    kolb_refill_body<true, NS, false, false>(ZOIC_REFILL_ARGS);
-}
-template <int NS>   // STRICT over the rays the decision-safe FAST kernel listed
-__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_STRICT void kolb_refill_redo_kernel(ZOIC_REFILL_PARAMS)
-{
-    kolb_refill_body<true, NS, false, true>(ZOIC_REFILL_ARGS);
-}
-template <int NS>   // FAST, decisions unchecked (round 1's fast mode; ZOIC_PRECISION_FAST_UNCHECKED)
-__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_FAST void kolb_refill_fast_kernel(ZOIC_REFILL_PARAMS)
-{
-    kolb_refill_body<false, NS, false, false>(ZOIC_REFILL_ARGS);
-}
-template <int NS>   // FAST, decision-safe (ZOIC_PRECISION_FAST)
-__global__ __launch_bounds__(kRefillBlock) ZOIC_REFILL_ATTR_FAST void kolb_refill_guard_kernel(ZOIC_REFILL_PARAMS)
-{
-    kolb_refill_body<false, NS, true, false>(ZOIC_REFILL_ARGS);
-}
+        uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, const uint32_t *__restrict__ srcList,          \
+        const unsigned int *__restrict__ srcCount, uint32_t *__restrict__ heavyList, unsigned int *__restrict__ heavyCount,                  \
+        uint32_t *__restrict__ redoList, unsigned int *__restrict__ redoCount, uint32_t heavyTries
+#define ZOIC_REFILL_ARGS T, B, samples, n, out, ldsWords, minSearching
+#define ZOIC_REFILL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_, LISTED_, DROPH_)                                                     \
+    template <int NS>                                                                                                        \
+    __global__ __launch_bounds__(kRefillBlock) ATTR_ void NAME_(ZOIC_REFILL_PARAMS)                                           \
+    {                                                                                                                        \
+        kolb_refill_body<STRICT_, NS, GUARD_, LISTED_, DROPH_>(ZOIC_REFILL_ARGS);                                             \
+    }
+ZOIC_REFILL_KERNEL(kolb_refill_strict_kernel, ZOIC_REFILL_ATTR_STRICT, true, false, false, true)          // STRICT, whole batch
+ZOIC_REFILL_KERNEL(kolb_refill_strict_listed_kernel, ZOIC_REFILL_ATTR_STRICT, true, false, true, false)   // STRICT over a work list (heavy / redo)
+ZOIC_REFILL_KERNEL(kolb_refill_fast_kernel, ZOIC_REFILL_ATTR_FAST, false, false, false, true)             // FAST unchecked, whole batch
+ZOIC_REFILL_KERNEL(kolb_refill_fast_listed_kernel, ZOIC_REFILL_ATTR_FAST, false, false, true, false)      // FAST unchecked over the heavy list
+ZOIC_REFILL_KERNEL(kolb_refill_guard_kernel, ZOIC_REFILL_ATTR_FAST, false, true, false, true)             // FAST decision-safe, whole batch
+ZOIC_REFILL_KERNEL(kolb_refill_guard_listed_kernel, ZOIC_REFILL_ATTR_FAST, false, true, true, false)      // FAST decision-safe over the heavy list
+#undef ZOIC_REFILL_KERNEL
 #undef ZOIC_REFILL_PARAMS
 #undef ZOIC_REFILL_ARGS
 
-// mode: 0 = STRICT, 1 = FAST decision-safe (needs d_redoList: room for every sample of the launch), 2 = FAST unchecked
+// mode: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked.  d_lists: two work lists of one dword per sample of the
+// launch each (heavy list, then redo list).
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                        uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                       int mode, uint32_t *d_redoList, void *stream)
+                       int mode, uint32_t *d_lists, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (mode == 1 && !d_redoList) return static_cast<int>(hipErrorInvalidValue);
+    if (!d_lists) return static_cast<int>(hipErrorInvalidValue);
     // one launch covers < 2^31 samples (32-bit ray offsets inside the kernel); larger batches are split
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;
+    const uint64_t listStride = n < kMaxPerLaunch ? n : kMaxPerLaunch;
+    uint32_t *heavyList = d_lists, *redoList = d_lists + listStride;
     for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
         const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
-        hipError_t e = reset_work_cursors(d_workCursor, st);   // both cursor sets and the work-list counter
+        hipError_t e = reset_work_cursors(d_workCursor, st);   // the three cursor sets and both work-list counters
         if (e != hipSuccess) return static_cast<int>(e);
         const unsigned grid = persistent_grid(m, kWavesPerBlock);
         const WorkGrain grain = work_grain(m);
         const uint32_t chunkRays = grain.chunkRays, chunksPerPart = grain.chunksPerPart;
         RayRecord *o = out + done;
         static const uint32_t minSearching = [] { const char *e = std::getenv("ZOIC_MIN_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kMinSearching; }();
+        static const uint32_t heavySearching = [] { const char *e = std::getenv("ZOIC_HEAVY_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kHeavySearching; }();
+        static const uint32_t heavyTries = [] { const char *e = std::getenv("ZOIC_HEAVY_TRIES"); return e ? static_cast<uint32_t>(std::atoi(e)) : kHeavyTries; }();
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
         const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
         // bokeh row cell records in LDS when the image is on and has them (4 KB at 256 rows, 32 KB at the 2048-row limit)
@@ -467,38 +514,50 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         // ZOIC_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the workgroups a CU admits
         static const size_t ldsPad = [] { const char *e = std::getenv("ZOIC_LDS_PAD"); return e ? static_cast<size_t>(std::atol(e)) : size_t(0); }();
         const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + kWavesPerBlock * 144 * sizeof(float4) + ldsPad +
-                                (mode == 1 ? kWavesPerBlock * kGuardLdsWords * sizeof(uint32_t) : 0);
-        unsigned int *redoCount = d_workCursor + kRedoCountOffset;
-        unsigned int *redoCursor = d_workCursor + kRedoCursorOffset;
-#define ZOIC_LAUNCH_REFILL(KERNEL_, NS_, CURSOR_, GRID_)                                                                        \
-    hipLaunchKernelGGL((KERNEL_<NS_>), dim3(GRID_), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp, rayBase + done,      \
-                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, minSearching, d_redoList, redoCount)
-#define ZOIC_LAUNCH_BY_COUNT(KERNEL_, CURSOR_, GRID_)                                                                           \
-    switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                   \
-    case 7: ZOIC_LAUNCH_REFILL(KERNEL_, 7, CURSOR_, GRID_); break;                                                              \
-    case 8: ZOIC_LAUNCH_REFILL(KERNEL_, 8, CURSOR_, GRID_); break;                                                              \
-    case 9: ZOIC_LAUNCH_REFILL(KERNEL_, 9, CURSOR_, GRID_); break;                                                              \
-    case 10: ZOIC_LAUNCH_REFILL(KERNEL_, 10, CURSOR_, GRID_); break;                                                            \
-    case 11: ZOIC_LAUNCH_REFILL(KERNEL_, 11, CURSOR_, GRID_); break;                                                            \
-    case 12: ZOIC_LAUNCH_REFILL(KERNEL_, 12, CURSOR_, GRID_); break;                                                            \
-    default: ZOIC_LAUNCH_REFILL(KERNEL_, 0, CURSOR_, GRID_); break;                                                             \
+                                kWavesPerBlock * kGuardLdsWords * sizeof(uint32_t);
+        unsigned int *redoCount = d_workCursor + kRedoCountOffset, *redoCursor = d_workCursor + kRedoCursorOffset;
+        unsigned int *heavyCount = d_workCursor + kHeavyCountOffset, *heavyCursor = d_workCursor + kHeavyCursorOffset;
+#define ZOIC_LAUNCH_REFILL(KERNEL_, NS_, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_)                                                \
+    hipLaunchKernelGGL((KERNEL_<NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp, rayBase + done,         \
+                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, SEARCHING_,          \
+                       static_cast<const uint32_t *>(SRCLIST_), static_cast<const unsigned int *>(SRCCOUNT_), heavyList, heavyCount, redoList, redoCount, heavyTries)
+#define ZOIC_LAUNCH_BY_COUNT(KERNEL_, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_)                                                   \
+    switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                     \
+    case 7: ZOIC_LAUNCH_REFILL(KERNEL_, 7, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                  \
+    case 8: ZOIC_LAUNCH_REFILL(KERNEL_, 8, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                  \
+    case 9: ZOIC_LAUNCH_REFILL(KERNEL_, 9, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                  \
+    case 10: ZOIC_LAUNCH_REFILL(KERNEL_, 10, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                \
+    case 11: ZOIC_LAUNCH_REFILL(KERNEL_, 11, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                \
+    case 12: ZOIC_LAUNCH_REFILL(KERNEL_, 12, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                \
+    default: ZOIC_LAUNCH_REFILL(KERNEL_, 0, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                 \
     }
-        if (mode == 0) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_kernel, d_workCursor, grid) }
-        else if (mode == 2) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_kernel, d_workCursor, grid) }
-        else {
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_kernel, d_workCursor, grid)
-            e = hipGetLastError();
-            if (e != hipSuccess) return static_cast<int>(e);
-            // the rays it listed, in the reference's arithmetic; workgroups beyond the list's length retire at once
-            static const bool dbg = std::getenv("ZOIC_DEBUG_REDO") != nullptr;   // experiments: how long is the work list?
-            if (dbg) {
-                unsigned int c = 0;
-                (void)hipStreamSynchronize(st);
-                (void)hipMemcpy(&c, redoCount, sizeof(c), hipMemcpyDeviceToHost);
-                std::fprintf(stderr, "[zoic] decision-safe fast: %u of %llu rays handed to the strict kernel (%.3g)\n", c, static_cast<unsigned long long>(m), double(c) / double(m));
-            }
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_redo_kernel, redoCursor, grid)
+#define ZOIC_CHECK_LAUNCH() e = hipGetLastError(); if (e != hipSuccess) return static_cast<int>(e)
+        // workgroups of a LISTED kernel beyond its list's length retire at once
+        if (mode == 0) {
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_kernel, d_workCursor, nullptr, nullptr, minSearching)
+            ZOIC_CHECK_LAUNCH();
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching)
+        } else if (mode == 2) {
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_kernel, d_workCursor, nullptr, nullptr, minSearching)
+            ZOIC_CHECK_LAUNCH();
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching)
+        } else {
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_kernel, d_workCursor, nullptr, nullptr, minSearching)
+            ZOIC_CHECK_LAUNCH();
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching)
+            ZOIC_CHECK_LAUNCH();
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, redoCursor, redoList, redoCount, minSearching)
         }
+        static const bool dbg = std::getenv("ZOIC_DEBUG_LISTS") != nullptr;   // experiments: how long are the work lists?
+        if (dbg) {
+            unsigned int h = 0, r = 0;
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(&h, heavyCount, sizeof(h), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&r, redoCount, sizeof(r), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[zoic] %llu rays: %u search-heavy (%.3g), %u to the strict kernel (%.3g)\n", static_cast<unsigned long long>(m), h,
+                         double(h) / double(m), r, double(r) / double(m));
+        }
+#undef ZOIC_CHECK_LAUNCH
 #undef ZOIC_LAUNCH_BY_COUNT
 #undef ZOIC_LAUNCH_REFILL
         e = hipGetLastError();
@@ -510,6 +569,15 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
 }  // namespace zoic
 
 #ifdef ZOIC_REGION_TIMERS
+extern "C" int zoic_debug_pass_stats(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(zoic::g_passStats), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(zoic::g_passStats), z, sizeof(z));
+    }
+    return static_cast<int>(e);
+}
 extern "C" int zoic_debug_region_cycles(unsigned long long *out8, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(zoic::g_regionCycles), 8 * sizeof(unsigned long long));
