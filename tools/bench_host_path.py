@@ -14,7 +14,8 @@ def main(n=1 << 24, reps=4):
     s = synthetic_samples(n, c["width"], c["height"], c["spp"])
     res = {}
     def timed(sp, rp, tag):
-        lib.zoic_create_rays_host(cam._h, n, sp, None, 0, rp)
+        for _ in range(4):   # the PCIe link / copy engines take a few transfers to reach their steady rate
+            lib.zoic_create_rays_host(cam._h, n, sp, None, 0, rp)
         t = time.perf_counter()
         for _ in range(reps):
             cam._check(lib.zoic_create_rays_host(cam._h, n, sp, None, 0, rp))

@@ -129,8 +129,13 @@ struct LaunchSlot {
 // Private scratch of ONE host-buffer call in flight: leased from the camera's pool for the duration of the call.
 // Two streams / two buffer sets: piece k+1 is copied in while piece k is traced and copied out.
 struct CallContext {
-    hipStream_t stream[2] = {nullptr, nullptr};
-    hipEvent_t landed[2] = {nullptr, nullptr};   // D2H of a piece has landed in hRays[b]
+    // Three streams: copy-in, kernels, copy-out.  PCIe is full duplex and the copy engines run beside the compute units,
+    // so with the three stages of consecutive pieces chained only through events (and two buffer sets) the call runs at
+    // the rate of its slowest stage -- normally the 32 B/ray copy-out.
+    hipStream_t sIn = nullptr, sRun = nullptr, sOut = nullptr;
+    hipEvent_t inDone[2] = {nullptr, nullptr};    // piece's samples are in dSamples[b]
+    hipEvent_t runDone[2] = {nullptr, nullptr};   // piece's kernels have finished (dSamples[b] free, dRays[b] full)
+    hipEvent_t outDone[2] = {nullptr, nullptr};   // piece's records have left dRays[b] (landed in the caller's / hRays[b] memory)
     DeviceBuffer<float> dSamples[2], dInputs7[2];
     DeviceBuffer<RayRecord> dRays[2];
     DeviceBuffer<uint32_t> dRng[2];
@@ -138,18 +143,32 @@ struct CallContext {
     PinnedBuffer one;                            // per-sample adapter: {sample 16 B, rng state 16 B, ray record 32 B}, zero-copy
     hipError_t init()
     {
-        for (int b = 0; b < 2; ++b) {
-            hipError_t e = hipStreamCreateWithFlags(&stream[b], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&landed[b], hipEventDisableTiming);
-            if (e != hipSuccess) return e;
+        hipError_t e = hipStreamCreateWithFlags(&sIn, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sRun, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&sOut, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+            e = hipEventCreateWithFlags(&inDone[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&runDone[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&outDone[b], hipEventDisableTiming);
         }
+        if (e != hipSuccess) return e;
         return one.reserve(64);
+    }
+    hipError_t sync_all()
+    {
+        hipError_t e = hipSuccess;
+        for (hipStream_t st : {sIn, sRun, sOut}) {
+            const hipError_t x = st ? hipStreamSynchronize(st) : hipSuccess;
+            if (x != hipSuccess && e == hipSuccess) e = x;
+        }
+        return e;
     }
     void release()
     {
+        (void)sync_all();
+        for (hipStream_t *st : {&sIn, &sRun, &sOut}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
         for (int b = 0; b < 2; ++b) {
-            if (stream[b]) { (void)hipStreamSynchronize(stream[b]); (void)hipStreamDestroy(stream[b]); stream[b] = nullptr; }
-            if (landed[b]) { (void)hipEventDestroy(landed[b]); landed[b] = nullptr; }
+            for (hipEvent_t *ev : {&inDone[b], &runDone[b], &outDone[b]}) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
             dSamples[b].release(); dInputs7[b].release(); dRays[b].release(); dRng[b].release(); hRays[b].release();
         }
         one.release();
@@ -837,10 +856,10 @@ zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_s
     ContextLease lease(cam);
     if (!lease) return fail(ZOIC_ERR_HIP, std::string("call context: ") + hipGetErrorString(lease.error()));
     CallContext &C = *lease;
-    // Pieces alternate between the context's two streams: while piece k is traced and copied out, piece k+1 is copied in
-    // (PCIe is full duplex).  Operations on one stream are ordered, so the per-stream device buffers need no host-side
-    // bookkeeping.  With page-locked caller buffers (zoic_host_alloc / zoic_host_register) every copy is truly
-    // asynchronous; with pageable ones hipMemcpyAsync stages internally and the pipeline degrades gracefully.
+    // Pieces run through the context's three streams (copy-in, kernels, copy-out), chained by events, on two buffer sets:
+    // while piece k is copied out, piece k+1 is traced and piece k+2 is copied in.  With page-locked caller buffers
+    // (zoic_host_alloc / zoic_host_register) every copy is truly asynchronous; with pageable ones hipMemcpyAsync stages
+    // internally and the pipeline degrades gracefully.
     const uint64_t piece = host_piece(n);
     const size_t cap = static_cast<size_t>(std::min<uint64_t>(n, piece));
     for (int b = 0; b < 2 && (b == 0 || n > piece); ++b) {
@@ -853,21 +872,31 @@ zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_s
     for (uint64_t off = 0; off < n && status == ZOIC_OK; off += piece, ++k) {
         const int b = static_cast<int>(k & 1u);
         const uint64_t m = std::min<uint64_t>(piece, n - off);
-        hipStream_t st = C.stream[b];
-        hipError_t e = hipMemcpyAsync(C.dSamples[b].ptr, h_samples + off * 4, m * 16, hipMemcpyHostToDevice, st);
+        hipError_t e = hipSuccess;
+        // copy-in: dSamples[b] is free once the kernels of piece k-2 are done
+        if (k >= 2) e = hipStreamWaitEvent(C.sIn, C.runDone[b], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(C.dSamples[b].ptr, h_samples + off * 4, m * 16, hipMemcpyHostToDevice, C.sIn);
         const uint32_t *dRng = nullptr;
         if (e == hipSuccess && h_rng_states) {
-            e = hipMemcpyAsync(C.dRng[b].ptr, h_rng_states + off * 4, m * 16, hipMemcpyHostToDevice, st);
+            e = hipMemcpyAsync(C.dRng[b].ptr, h_rng_states + off * 4, m * 16, hipMemcpyHostToDevice, C.sIn);
             dRng = C.dRng[b].ptr;
         }
+        if (e == hipSuccess) e = hipEventRecord(C.inDone[b], C.sIn);
+        // kernels: need the samples, and dRays[b] back from the copy-out of piece k-2
+        if (e == hipSuccess) e = hipStreamWaitEvent(C.sRun, C.inDone[b], 0);
+        if (e == hipSuccess && k >= 2) e = hipStreamWaitEvent(C.sRun, C.outDone[b], 0);
         if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e)); break; }
-        status = launch_rays(cam, m, C.dSamples[b].ptr, dRng, ray_index_base + off, C.dRays[b].ptr, st);
+        status = launch_rays(cam, m, C.dSamples[b].ptr, dRng, ray_index_base + off, C.dRays[b].ptr, C.sRun);
         if (status != ZOIC_OK) break;
-        e = hipMemcpyAsync(h_rays + off, C.dRays[b].ptr, m * sizeof(zoic_ray), hipMemcpyDeviceToHost, st);
+        e = hipEventRecord(C.runDone[b], C.sRun);
+        // copy-out
+        if (e == hipSuccess) e = hipStreamWaitEvent(C.sOut, C.runDone[b], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_rays + off, C.dRays[b].ptr, m * sizeof(zoic_ray), hipMemcpyDeviceToHost, C.sOut);
+        if (e == hipSuccess) e = hipEventRecord(C.outDone[b], C.sOut);
         if (e != hipSuccess) status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
     }
-    for (int b = 0; b < 2; ++b) {   // own streams only: other threads' calls are not waited for
-        const hipError_t e = hipStreamSynchronize(C.stream[b]);
+    {   // own streams only: other threads' calls are not waited for
+        const hipError_t e = C.sync_all();
         if (e != hipSuccess && status == ZOIC_OK) status = fail(ZOIC_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(e));
     }
     return status;
@@ -885,8 +914,8 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
     ContextLease lease(cam);
     if (!lease) return fail(ZOIC_ERR_HIP, std::string("call context: ") + hipGetErrorString(lease.error()));
     CallContext &C = *lease;
-    // Same two-stream pipeline as zoic_create_rays_host; the 32-byte records land in the context's pinned buffers and the
-    // host expands piece k into AtCameraOutput layout while piece k+1 is on the GPU.
+    // Same three-stream pipeline as zoic_create_rays_host; the 32-byte records land in the context's pinned buffers and the
+    // host expands piece k into AtCameraOutput layout while pieces k+1, k+2 are on the GPU / on the wire.
     const uint64_t piece = host_piece(n);
     const size_t cap = static_cast<size_t>(std::min<uint64_t>(n, piece));
     for (int b = 0; b < 2 && (b == 0 || n > piece); ++b) {
@@ -899,7 +928,7 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
     uint64_t k = 0, prevOff = 0, prevM = 0;
     int prevB = -1;
     const auto expand_piece = [&](int b, uint64_t off, uint64_t m) -> hipError_t {
-        const hipError_t e = hipEventSynchronize(C.landed[b]);
+        const hipError_t e = hipEventSynchronize(C.outDone[b]);
         if (e != hipSuccess) return e;
         const zoic_ray *r = static_cast<const zoic_ray *>(C.hRays[b].host);
         for (uint64_t i = 0; i < m; ++i) expand_record(r[i], outputs[off + i]);
@@ -908,14 +937,21 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
     for (uint64_t off = 0; off < n && status == ZOIC_OK; off += piece, ++k) {
         const int b = static_cast<int>(k & 1u);
         const uint64_t m = std::min<uint64_t>(piece, n - off);
-        hipStream_t st = C.stream[b];
-        hipError_t e = hipMemcpyAsync(C.dInputs7[b].ptr, inputs + off, m * sizeof(zoic_camera_input), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = static_cast<hipError_t>(launch_pack_inputs(C.dInputs7[b].ptr, C.dSamples[b].ptr, m, st));
+        hipError_t e = hipSuccess;
+        // hRays[b] is read by the host's expansion of piece k-2, which ran (below) before this iteration: free.
+        if (k >= 2) e = hipStreamWaitEvent(C.sIn, C.runDone[b], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(C.dInputs7[b].ptr, inputs + off, m * sizeof(zoic_camera_input), hipMemcpyHostToDevice, C.sIn);
+        if (e == hipSuccess) e = hipEventRecord(C.inDone[b], C.sIn);
+        if (e == hipSuccess) e = hipStreamWaitEvent(C.sRun, C.inDone[b], 0);
+        if (e == hipSuccess && k >= 2) e = hipStreamWaitEvent(C.sRun, C.outDone[b], 0);
+        if (e == hipSuccess) e = static_cast<hipError_t>(launch_pack_inputs(C.dInputs7[b].ptr, C.dSamples[b].ptr, m, C.sRun));
         if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("H2D + pack: ") + hipGetErrorString(e)); break; }
-        status = launch_rays(cam, m, C.dSamples[b].ptr, nullptr, ray_index_base + off, C.dRays[b].ptr, st);
+        status = launch_rays(cam, m, C.dSamples[b].ptr, nullptr, ray_index_base + off, C.dRays[b].ptr, C.sRun);
         if (status != ZOIC_OK) break;
-        e = hipMemcpyAsync(C.hRays[b].host, C.dRays[b].ptr, m * sizeof(zoic_ray), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipEventRecord(C.landed[b], st);
+        e = hipEventRecord(C.runDone[b], C.sRun);
+        if (e == hipSuccess) e = hipStreamWaitEvent(C.sOut, C.runDone[b], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(C.hRays[b].host, C.dRays[b].ptr, m * sizeof(zoic_ray), hipMemcpyDeviceToHost, C.sOut);
+        if (e == hipSuccess) e = hipEventRecord(C.outDone[b], C.sOut);
         if (e == hipSuccess && prevB >= 0) e = expand_piece(prevB, prevOff, prevM);   // overlaps this piece's GPU work
         if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e)); break; }
         prevB = b; prevOff = off; prevM = m;
@@ -924,7 +960,7 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
         const hipError_t e = expand_piece(prevB, prevOff, prevM);
         if (e != hipSuccess) status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
     }
-    if (status != ZOIC_OK) for (int b = 0; b < 2; ++b) (void)hipStreamSynchronize(C.stream[b]);   // nothing of ours left in flight
+    if (status != ZOIC_OK) (void)C.sync_all();   // nothing of ours left in flight
     return status;
 }
 
@@ -951,8 +987,8 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
     Block *d = static_cast<Block *>(C.one.dev);
     h->sample[0] = input->sx; h->sample[1] = input->sy; h->sample[2] = input->lensx; h->sample[3] = input->lensy;
     h->rng[0] = rng.x; h->rng[1] = rng.y; h->rng[2] = rng.z; h->rng[3] = rng.w;
-    if (zoic_status s = launch_rays(cam, 1, d->sample, d->rng, 0, reinterpret_cast<RayRecord *>(&d->ray), C.stream[0])) return s;
-    ZOIC_HIP(hipStreamSynchronize(C.stream[0]));
+    if (zoic_status s = launch_rays(cam, 1, d->sample, d->rng, 0, reinterpret_cast<RayRecord *>(&d->ray), C.sRun)) return s;
+    ZOIC_HIP(hipStreamSynchronize(C.sRun));
     const zoic_ray r = h->ray;
     // every retry drew two numbers (zoic.cpp:1806 / 1881 / 1930), whether or not the kernel short-cut them
     const uint32_t tries = (r.flags >> 1) & 31u;
