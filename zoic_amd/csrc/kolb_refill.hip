@@ -532,19 +532,21 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
     default: ZOIC_LAUNCH_REFILL(KERNEL_, 0, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                 \
     }
 #define ZOIC_CHECK_LAUNCH() e = hipGetLastError(); if (e != hipSuccess) return static_cast<int>(e)
-        // workgroups of a LISTED kernel beyond its list's length retire at once
+        // workgroups of a LISTED kernel beyond its list's length retire at once; the heavy-list kernel is not launched at all
+        // while no ray can qualify (the default: a ray has at most kMaxTries + 1 draws)
+        const bool heavyOn = heavyTries <= static_cast<uint32_t>(kMaxTries);
         if (mode == 0) {
             ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_kernel, d_workCursor, nullptr, nullptr, minSearching)
             ZOIC_CHECK_LAUNCH();
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching)
+            if (heavyOn) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching) }
         } else if (mode == 2) {
             ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_kernel, d_workCursor, nullptr, nullptr, minSearching)
             ZOIC_CHECK_LAUNCH();
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching)
+            if (heavyOn) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching) }
         } else {
             ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_kernel, d_workCursor, nullptr, nullptr, minSearching)
             ZOIC_CHECK_LAUNCH();
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching)
+            if (heavyOn) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching) }
             ZOIC_CHECK_LAUNCH();
             ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, redoCursor, redoList, redoCount, minSearching)
         }

@@ -101,6 +101,7 @@ class ShardedFrame:
         torch, dist = self.torch, self.dist
         mine = self.chunks[self.rank]
         pending = []
+        stage_busy = [None, None]   # the sends still reading each staging buffer
         for k in range(self.rounds):
             rec = None
             if k < len(mine):
@@ -118,9 +119,11 @@ class ShardedFrame:
                         ops.append(dist.P2POp(dist.irecv, self.full[ra:rb], r))
             elif rec is not None:
                 buf = self.stage[k & 1][: b - a]
-                if self.cuda and len(pending) >= 2:
-                    for q in pending.pop(0):            # the send that used this staging buffer two rounds ago
+                if stage_busy[k & 1] is not None:
+                    for q in stage_busy[k & 1]:         # the send that used this staging buffer two rounds ago
                         q.wait()
+                    pending.remove(stage_busy[k & 1])   # a gloo send request must be waited for exactly once
+                    stage_busy[k & 1] = None
                 buf.copy_(rec[:, :self.k])             # 32-byte records -> 28-byte payload, on the compute stream
                 ops.append(dist.P2POp(dist.isend, buf, self.dst))
             if ops:
@@ -129,9 +132,12 @@ class ShardedFrame:
                     # chunk k while the next iteration's kernel runs on the compute stream
                     self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                     with torch.cuda.stream(self.comm_stream):
-                        pending.append(dist.batch_isend_irecv(ops))
+                        reqs = dist.batch_isend_irecv(ops)
                 else:
-                    pending.append(dist.batch_isend_irecv(ops))
+                    reqs = dist.batch_isend_irecv(ops)
+                pending.append(reqs)
+                if self.rank != self.dst:
+                    stage_busy[k & 1] = reqs
         for reqs in pending:
             for q in reqs:
                 q.wait()
