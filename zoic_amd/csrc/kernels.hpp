@@ -28,17 +28,15 @@ struct DeviceCounters {  // zoic.cpp:533-534: succesRays, vignettedRays, totalIn
 // by the L2, different addresses in parallel; a wave starts on its workgroup's home partition and moves on when it is empty.
 constexpr unsigned kCursorParts = 8;
 constexpr unsigned kCursorPartStride = 64;   // 256 bytes apart
-// The same 2 KB block also holds the work lists' counters and the cursor sets of the LISTED kernels (kolb_refill.hip), each
-// on its own 64-byte line; the one memset per launch zeroes all of it.  Dword offsets into the block:
-constexpr unsigned kRedoCountOffset = 32;     // length of the STRICT kernel's work list (decision-safe FAST mode)
+// The same 2 KB block also holds what the decision-safe FAST mode needs (kolb_refill.hip), each on its own 64-byte line;
+// the one memset per launch zeroes all of it.  Dword offsets into the block:
+constexpr unsigned kRedoCountOffset = 32;     // length of the STRICT kernel's work list
 constexpr unsigned kRedoCursorOffset = 16;    // partition p's cursor of that kernel: block[16 + p * kCursorPartStride]
-constexpr unsigned kHeavyCountOffset = 32 + kCursorPartStride;   // length of the search-heavy work list
-constexpr unsigned kHeavyCursorOffset = 48;   // partition p's cursor of the heavy kernel: block[48 + p * kCursorPartStride]
-// precision modes of the Kolb launch (zoic_precision): 0 strict, 1 fast decision-safe, 2 fast unchecked.
-// d_lists: 2 x min(n, 2^31) dwords of scratch for the two work lists.
+// precision modes of the Kolb launch (zoic_precision): 0 strict, 1 fast decision-safe (d_redoList: min(n, 2^31) dwords of
+// scratch for the work list), 2 fast unchecked
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                     int mode, uint32_t *d_lists, void *stream);
+                     int mode, uint32_t *d_redoList, void *stream);
 
 // camera_create_ray, THINLENS branch (zoic.cpp:1771-1846).  With optical vignetting on (retries possible) the
 // persistent-wave refill kernel of thin_refill.hip runs, otherwise the streaming kernel; ZOIC_THIN_VARIANT=simple

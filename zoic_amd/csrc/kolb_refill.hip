@@ -76,10 +76,7 @@ __device__ unsigned long long g_passStats[8];   // passes, sum active lanes, sea
 struct RefillArgs {
     KolbTable T; BokehTables B; const float4 *samples; const uint4 *rngStates; uint64_t rayBase; uint32_t n; RayRecord *out;
     DeviceCounters *counters; unsigned int *workCursor; uint32_t ldsWords, chunkRays, chunksPerPart, minSearching;
-    const uint32_t *srcList; const unsigned int *srcCount;   // LISTED kernels: the ray indices to evaluate
-    uint32_t *heavyList; unsigned int *heavyCount;           // DROPH kernels: rays handed to the search-heavy kernel
-    uint32_t *redoList; unsigned int *redoCount;             // GUARD kernels: rays handed to the STRICT kernel
-    uint32_t heavyTries;                                     // DROPH kernels: draws without a candidate that make a ray search-heavy
+    uint32_t *redoList; unsigned int *redoCount;             // GUARD kernel: appends the rays it cannot decide; LISTED kernel: reads them
 };
 template <class V, size_t OFFSET>
 __device__ __forceinline__ V kernarg_field()
@@ -91,35 +88,28 @@ __device__ __forceinline__ V kernarg_field()
 }
 #define ZOIC_KARG(field) kernarg_field<decltype(RefillArgs::field), offsetof(RefillArgs, field)>()
 
-// One body, six kernels.  A launch is a short pipeline of persistent kernels on the caller's stream; rays move between them
-// through compact work lists of ray indices (a dropped ray leaves no record and no counter behind and is evaluated from
-// scratch by the kernel that picks it up -- per-ray retry streams make that the same ray):
-//   main kernel (STRICT | FAST | FAST+GUARD, DROPH): the whole batch.  Drops (a) "search-heavy" rays -- still without a
-//       candidate after kHeavyTries draws: in practice pixels whose exit pupil is (almost) fully vignetted, 26 cheap draws
-//       each -- to heavyList; (b) GUARD only: rays with an accept/reject decision too close to call to redoList.
-//   heavy kernel (same arithmetic, LISTED over heavyList): every lane is a searcher, the draw loop runs at full lane
-//       utilisation (minSearching 1) instead of 12 searchers riding along 50 tracers pass after pass (C2: 55 % lane
-//       utilisation in round 1).  GUARD: may add to redoList.
-//   redo kernel (STRICT, LISTED over redoList; decision-safe FAST mode only): the reference's arithmetic for the rays whose
-//       stop clip FAST could not call (tables.hpp FastSurface::bandHousing).  Together: every ray's try count, weight and
-//       flags are the reference's; only the low-order bits of origin / direction of the FAST-evaluated rays differ.
-// Drops are staged in the wave's own LDS list, branch-free, every pass, and moved to the global lists in whole batches
-// OUTSIDE the pass loop (a wave-uniform rare block with an atomic inside the pass loop makes LLVM spill ~60 more SGPRs to
-// VGPR lanes: 320 v_readlane against 90, +12-20 % kernel time).  TIR bumps are tallied per ray (above bit 0 of lutMiss) and
-// reach the counters only when the ray finishes in this kernel.
-constexpr uint32_t kHeavyTries = 1000;     // draws without a candidate after which a ray counts as search-heavy; 1000 = never (measured: the split loses); ZOIC_HEAVY_TRIES overrides
-constexpr uint32_t kHeavySearching = 40;   // heavy kernel: the draw loop spins while at least this many lanes are looking
-constexpr uint32_t kHeavyTag = 0x80000000u;  // staged entry: heavy (else: to the STRICT kernel); ray indices are < 2^31
-
-template <bool STRICT, int NS, bool GUARD, bool LISTED, bool DROPH>
+// One body, four kernels.  A decision-safe FAST launch is a pipeline of two persistent kernels on the caller's stream:
+//   GUARD (FAST only): every accept/reject decision of a try at a guarded interface (tables.hpp FastSurface::bandHousing:
+//       in practice the stop) is checked against its guard band; a ray with a decision too close to call is dropped where
+//       it stands -- no record, no counter -- and its index goes to the work list `redoList`;
+//   LISTED (STRICT only) = the kernel that runs next on the stream and evaluates exactly the listed rays from scratch in
+//       the reference's arithmetic (per-ray retry streams make that the same ray).
+// Together: every ray's try count, weight and flags are the reference's; only the low-order bits of origin / direction of
+// the FAST-evaluated rays differ.  Drops are staged in the wave's own LDS list, branch-free, every pass, and moved to the
+// global list in whole batches OUTSIDE the pass loop (a wave-uniform rare block with an atomic inside the pass loop makes
+// LLVM spill ~60 more SGPRs to VGPR lanes: 320 v_readlane against 90, +12-20 % kernel time).  TIR bumps are tallied per
+// ray (above bit 0 of lutMiss) and reach the counters only when the ray finishes in this kernel.
+// (A third role -- handing "search-heavy" rays, still without a candidate after a few draws, to a kernel where every lane
+// is a searcher -- was built on the same lists and measured twice: it loses 10-40 %; removed.)
+template <bool STRICT, int NS, bool GUARD, bool LISTED>
 __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
                                                  uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching)
 {
-    static_assert(!(GUARD && STRICT) && !(LISTED && DROPH), "GUARD is a FAST mode; only main kernels drop search-heavy rays");
-    constexpr bool DEFER = GUARD || DROPH;   // this kernel may hand rays on
+    static_assert(!(GUARD && STRICT) && !(LISTED && !STRICT), "GUARD is a FAST mode, LISTED the STRICT kernel behind it");
+    constexpr bool DEFER = GUARD;   // this kernel may hand rays on
     uint32_t redoChunk = 0, redoChunksPerPart = 0;
     if constexpr (LISTED) {   // the work list's length is only known on the device
-        n = *ZOIC_KARG(srcCount);   // <= samples of the launch, which is what the list was sized for
+        n = *ZOIC_KARG(redoCount);   // <= samples of the launch, which is what the list was sized for
         if (n == 0u) return;
         // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times
         // over: a claim costs three dependent round trips (cursor, list, samples) and is amortised over the chunk
@@ -167,7 +157,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     if constexpr (DEFER) tirLds[lane] = 0u;
     const auto fetch_window = [&](uint32_t base) {
         const uint32_t wi = base + lane;
-        if constexpr (LISTED) { winIdx = ZOIC_KARG(srcList)[wi < n ? wi : n - 1]; win = samples[winIdx]; }
+        if constexpr (LISTED) { winIdx = ZOIC_KARG(redoList)[wi < n ? wi : n - 1]; win = samples[winIdx]; }
         else win = samples[wi < n ? wi : n - 1];
         winBase = base;
     };
@@ -379,14 +369,12 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         const bool finished = active && !searching && (ok || tries > static_cast<uint32_t>(kMaxTries)) && !(GUARD && unsure);
         if constexpr (DEFER) {
             // stage the dropped rays' indices, add the finished rays' TIR tallies (LDS traffic only)
-            const bool dropU = GUARD && active && unsure;
-            const bool dropH = DROPH && active && searching && !unsure && tries >= ZOIC_KARG(heavyTries);   // still no candidate: search-heavy
-            const bool drop = dropU || dropH;
+            const bool drop = active && unsure;
             const uint32_t tally = finished ? (lutMiss >> 1) : 0u;
             if (__ballot(drop || tally != 0u) != 0ull) {
                 const unsigned long long dropMask = __ballot(drop);
                 const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dropMask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dropMask), 0u));
-                if (drop) { dropLds[dropCnt + r] = idx | (dropU ? 0u : kHeavyTag); active = false; }
+                if (drop) { dropLds[dropCnt + r] = idx; active = false; }
                 dropCnt += static_cast<uint32_t>(__popcll(dropMask));
                 if (tally != 0u) tirLds[lane] += tally;
             }
@@ -410,33 +398,13 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         if constexpr (DEFER) { if (dropCnt > 64u) break; }   // the LDS list must keep room for a whole pass: flush below
     }
     if constexpr (DEFER) {
-        // move the staged indices to the global work lists: per list ONE atomic reserves exactly the entries written
+        // move the staged indices to the STRICT kernel's work list: one atomic reserves exactly the entries written
         if (dropCnt != 0u) {
-            for (uint32_t base = 0; base < dropCnt; base += 64u) {
-                const uint32_t j = base + lane;
-                const uint32_t e = j < dropCnt ? dropLds[j] : 0u;
-                const bool heavy = j < dropCnt && (e & kHeavyTag) != 0u, unsureRay = j < dropCnt && (e & kHeavyTag) == 0u;
-                if constexpr (DROPH) {
-                    const unsigned long long m = __ballot(heavy);
-                    if (m != 0ull) {
-                        uint32_t at = 0;
-                        if (lane == 0) at = atomicAdd(ZOIC_KARG(heavyCount), static_cast<unsigned int>(__popcll(m)));
-                        at = __builtin_amdgcn_readfirstlane(at);
-                        const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-                        if (heavy) ZOIC_KARG(heavyList)[at + r] = e & ~kHeavyTag;
-                    }
-                }
-                if constexpr (GUARD) {
-                    const unsigned long long m = __ballot(unsureRay);
-                    if (m != 0ull) {
-                        uint32_t at = 0;
-                        if (lane == 0) at = atomicAdd(ZOIC_KARG(redoCount), static_cast<unsigned int>(__popcll(m)));
-                        at = __builtin_amdgcn_readfirstlane(at);
-                        const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-                        if (unsureRay) ZOIC_KARG(redoList)[at + r] = e;
-                    }
-                }
-            }
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(ZOIC_KARG(redoCount), dropCnt);
+            at = __builtin_amdgcn_readfirstlane(at);
+            uint32_t *list = ZOIC_KARG(redoList);
+            for (uint32_t j = lane; j < dropCnt; j += 64u) list[at + j] = dropLds[j];
             dropCnt = 0;
         }
     }
@@ -464,49 +432,41 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
 // the precisions / roles are separate kernels so that each can carry its own register-budget attributes
 #define ZOIC_REFILL_PARAMS const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, \
         uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,          \
-        uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, const uint32_t *__restrict__ srcList,          \
-        const unsigned int *__restrict__ srcCount, uint32_t *__restrict__ heavyList, unsigned int *__restrict__ heavyCount,                  \
-        uint32_t *__restrict__ redoList, unsigned int *__restrict__ redoCount, uint32_t heavyTries
+        uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList,               \
+        unsigned int *__restrict__ redoCount
 #define ZOIC_REFILL_ARGS T, B, samples, n, out, ldsWords, minSearching
-#define ZOIC_REFILL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_, LISTED_, DROPH_)                                                     \
+#define ZOIC_REFILL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_, LISTED_)                                                             \
     template <int NS>                                                                                                        \
     __global__ __launch_bounds__(kRefillBlock) ATTR_ void NAME_(ZOIC_REFILL_PARAMS)                                           \
     {                                                                                                                        \
-        kolb_refill_body<STRICT_, NS, GUARD_, LISTED_, DROPH_>(ZOIC_REFILL_ARGS);                                             \
+        kolb_refill_body<STRICT_, NS, GUARD_, LISTED_>(ZOIC_REFILL_ARGS);                                                     \
     }
-ZOIC_REFILL_KERNEL(kolb_refill_strict_kernel, ZOIC_REFILL_ATTR_STRICT, true, false, false, true)          // STRICT, whole batch
-ZOIC_REFILL_KERNEL(kolb_refill_strict_listed_kernel, ZOIC_REFILL_ATTR_STRICT, true, false, true, false)   // STRICT over a work list (heavy / redo)
-ZOIC_REFILL_KERNEL(kolb_refill_fast_kernel, ZOIC_REFILL_ATTR_FAST, false, false, false, true)             // FAST unchecked, whole batch
-ZOIC_REFILL_KERNEL(kolb_refill_fast_listed_kernel, ZOIC_REFILL_ATTR_FAST, false, false, true, false)      // FAST unchecked over the heavy list
-ZOIC_REFILL_KERNEL(kolb_refill_guard_kernel, ZOIC_REFILL_ATTR_FAST, false, true, false, true)             // FAST decision-safe, whole batch
-ZOIC_REFILL_KERNEL(kolb_refill_guard_listed_kernel, ZOIC_REFILL_ATTR_FAST, false, true, true, false)      // FAST decision-safe over the heavy list
+ZOIC_REFILL_KERNEL(kolb_refill_strict_kernel, ZOIC_REFILL_ATTR_STRICT, true, false, false)          // STRICT, whole batch
+ZOIC_REFILL_KERNEL(kolb_refill_strict_listed_kernel, ZOIC_REFILL_ATTR_STRICT, true, false, true)    // STRICT over the work list of the GUARD kernel
+ZOIC_REFILL_KERNEL(kolb_refill_fast_kernel, ZOIC_REFILL_ATTR_FAST, false, false, false)             // FAST unchecked (round 1's fast mode)
+ZOIC_REFILL_KERNEL(kolb_refill_guard_kernel, ZOIC_REFILL_ATTR_FAST, false, true, false)             // FAST decision-safe
 #undef ZOIC_REFILL_KERNEL
 #undef ZOIC_REFILL_PARAMS
 #undef ZOIC_REFILL_ARGS
 
-// mode: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked.  d_lists: two work lists of one dword per sample of the
-// launch each (heavy list, then redo list).
+// mode: 0 = STRICT, 1 = FAST decision-safe (d_redoList: one dword per sample of the launch), 2 = FAST unchecked
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                        uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                       int mode, uint32_t *d_lists, void *stream)
+                       int mode, uint32_t *d_redoList, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!d_lists) return static_cast<int>(hipErrorInvalidValue);
+    if (mode == 1 && !d_redoList) return static_cast<int>(hipErrorInvalidValue);
     // one launch covers < 2^31 samples (32-bit ray offsets inside the kernel); larger batches are split
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;
-    const uint64_t listStride = n < kMaxPerLaunch ? n : kMaxPerLaunch;
-    uint32_t *heavyList = d_lists, *redoList = d_lists + listStride;
     for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
         const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
-        hipError_t e = reset_work_cursors(d_workCursor, st);   // the three cursor sets and both work-list counters
+        hipError_t e = reset_work_cursors(d_workCursor, st);   // both cursor sets and the work list's counter
         if (e != hipSuccess) return static_cast<int>(e);
         const unsigned grid = persistent_grid(m, kWavesPerBlock);
         const WorkGrain grain = work_grain(m);
         const uint32_t chunkRays = grain.chunkRays, chunksPerPart = grain.chunksPerPart;
         RayRecord *o = out + done;
         static const uint32_t minSearching = [] { const char *e = std::getenv("ZOIC_MIN_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kMinSearching; }();
-        static const uint32_t heavySearching = [] { const char *e = std::getenv("ZOIC_HEAVY_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kHeavySearching; }();
-        static const uint32_t heavyTries = [] { const char *e = std::getenv("ZOIC_HEAVY_TRIES"); return e ? static_cast<uint32_t>(std::atoi(e)) : kHeavyTries; }();
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
         const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
         // bokeh row cell records in LDS when the image is on and has them (4 KB at 256 rows, 32 KB at the 2048-row limit)
@@ -514,52 +474,37 @@ int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const f
         // ZOIC_LDS_PAD (bytes): occupancy experiments only -- extra dynamic LDS lowers the workgroups a CU admits
         static const size_t ldsPad = [] { const char *e = std::getenv("ZOIC_LDS_PAD"); return e ? static_cast<size_t>(std::atol(e)) : size_t(0); }();
         const size_t ldsBytes = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + kWavesPerBlock * 144 * sizeof(float4) + ldsPad +
-                                kWavesPerBlock * kGuardLdsWords * sizeof(uint32_t);
+                                (mode == 1 ? kWavesPerBlock * kGuardLdsWords * sizeof(uint32_t) : 0);
         unsigned int *redoCount = d_workCursor + kRedoCountOffset, *redoCursor = d_workCursor + kRedoCursorOffset;
-        unsigned int *heavyCount = d_workCursor + kHeavyCountOffset, *heavyCursor = d_workCursor + kHeavyCursorOffset;
-#define ZOIC_LAUNCH_REFILL(KERNEL_, NS_, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_)                                                \
-    hipLaunchKernelGGL((KERNEL_<NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp, rayBase + done,         \
-                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, SEARCHING_,          \
-                       static_cast<const uint32_t *>(SRCLIST_), static_cast<const unsigned int *>(SRCCOUNT_), heavyList, heavyCount, redoList, redoCount, heavyTries)
-#define ZOIC_LAUNCH_BY_COUNT(KERNEL_, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_)                                                   \
-    switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                     \
-    case 7: ZOIC_LAUNCH_REFILL(KERNEL_, 7, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                  \
-    case 8: ZOIC_LAUNCH_REFILL(KERNEL_, 8, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                  \
-    case 9: ZOIC_LAUNCH_REFILL(KERNEL_, 9, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                  \
-    case 10: ZOIC_LAUNCH_REFILL(KERNEL_, 10, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                \
-    case 11: ZOIC_LAUNCH_REFILL(KERNEL_, 11, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                \
-    case 12: ZOIC_LAUNCH_REFILL(KERNEL_, 12, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                \
-    default: ZOIC_LAUNCH_REFILL(KERNEL_, 0, CURSOR_, SRCLIST_, SRCCOUNT_, SEARCHING_); break;                                                 \
+#define ZOIC_LAUNCH_REFILL(KERNEL_, NS_, CURSOR_)                                                                               \
+    hipLaunchKernelGGL((KERNEL_<NS_>), dim3(grid), dim3(kRefillBlock), ldsBytes, st, table, bokeh, sp, rp, rayBase + done,       \
+                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, minSearching, d_redoList, redoCount)
+#define ZOIC_LAUNCH_BY_COUNT(KERNEL_, CURSOR_)                                                                                  \
+    switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                   \
+    case 7: ZOIC_LAUNCH_REFILL(KERNEL_, 7, CURSOR_); break;                                                                     \
+    case 8: ZOIC_LAUNCH_REFILL(KERNEL_, 8, CURSOR_); break;                                                                     \
+    case 9: ZOIC_LAUNCH_REFILL(KERNEL_, 9, CURSOR_); break;                                                                     \
+    case 10: ZOIC_LAUNCH_REFILL(KERNEL_, 10, CURSOR_); break;                                                                   \
+    case 11: ZOIC_LAUNCH_REFILL(KERNEL_, 11, CURSOR_); break;                                                                   \
+    case 12: ZOIC_LAUNCH_REFILL(KERNEL_, 12, CURSOR_); break;                                                                   \
+    default: ZOIC_LAUNCH_REFILL(KERNEL_, 0, CURSOR_); break;                                                                    \
     }
-#define ZOIC_CHECK_LAUNCH() e = hipGetLastError(); if (e != hipSuccess) return static_cast<int>(e)
-        // workgroups of a LISTED kernel beyond its list's length retire at once; the heavy-list kernel is not launched at all
-        // while no ray can qualify (the default: a ray has at most kMaxTries + 1 draws)
-        const bool heavyOn = heavyTries <= static_cast<uint32_t>(kMaxTries);
-        if (mode == 0) {
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_kernel, d_workCursor, nullptr, nullptr, minSearching)
-            ZOIC_CHECK_LAUNCH();
-            if (heavyOn) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching) }
-        } else if (mode == 2) {
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_kernel, d_workCursor, nullptr, nullptr, minSearching)
-            ZOIC_CHECK_LAUNCH();
-            if (heavyOn) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching) }
-        } else {
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_kernel, d_workCursor, nullptr, nullptr, minSearching)
-            ZOIC_CHECK_LAUNCH();
-            if (heavyOn) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_listed_kernel, heavyCursor, heavyList, heavyCount, heavySearching) }
-            ZOIC_CHECK_LAUNCH();
-            ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, redoCursor, redoList, redoCount, minSearching)
+        if (mode == 0) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_kernel, d_workCursor) }
+        else if (mode == 2) { ZOIC_LAUNCH_BY_COUNT(kolb_refill_fast_kernel, d_workCursor) }
+        else {
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_guard_kernel, d_workCursor)
+            e = hipGetLastError();
+            if (e != hipSuccess) return static_cast<int>(e);
+            // the rays it listed, in the reference's arithmetic; workgroups beyond the list's length retire at once
+            ZOIC_LAUNCH_BY_COUNT(kolb_refill_strict_listed_kernel, redoCursor)
+            static const bool dbg = std::getenv("ZOIC_DEBUG_LISTS") != nullptr;   // experiments: how long is the work list?
+            if (dbg) {
+                unsigned int r = 0;
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(&r, redoCount, sizeof(r), hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "[zoic] %llu rays: %u handed to the strict kernel (%.3g)\n", static_cast<unsigned long long>(m), r, double(r) / double(m));
+            }
         }
-        static const bool dbg = std::getenv("ZOIC_DEBUG_LISTS") != nullptr;   // experiments: how long are the work lists?
-        if (dbg) {
-            unsigned int h = 0, r = 0;
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(&h, heavyCount, sizeof(h), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&r, redoCount, sizeof(r), hipMemcpyDeviceToHost);
-            std::fprintf(stderr, "[zoic] %llu rays: %u search-heavy (%.3g), %u to the strict kernel (%.3g)\n", static_cast<unsigned long long>(m), h,
-                         double(h) / double(m), r, double(r) / double(m));
-        }
-#undef ZOIC_CHECK_LAUNCH
 #undef ZOIC_LAUNCH_BY_COUNT
 #undef ZOIC_LAUNCH_REFILL
         e = hipGetLastError();
