@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_search.hpp"
+#include "exact_math.hpp"
 #include "fast_optics.hpp"
 #include "kernels.hpp"
 #include "optics.hpp"
@@ -54,29 +55,52 @@ __device__ __forceinline__ bool lut_lookup_lds(const float2 *lut, int lutSize, f
 // trace_lens_fast_pred: lanes that fail only clear their bit in `alive`; every surviving lane executes exactly the
 // reference's sequence of roundings, so alive lanes are bit-identical to the branchy version.  Rays that FINISH failed
 // get their partial state from trace_lens_strict.
+//
+// The four square roots and three reciprocals per interface use the LEAN correctly-rounded sequences of exact_math.hpp
+// without their per-call range guard (a guard branch would be taken by every wave: dead lanes ride along on garbage).
+// Instead one integer compare per root records whether an ALIVE lane ever left the verified range [1e-30, 1e30]
+// (`outOfRange`); the caller then re-runs that try through trace_lens_strict, whose roots are guarded.  In range the lean
+// sequences ARE the IEEE results (tools/ubench/exact_math_check.hip, all 2^32 inputs), so the bits do not change.
+__device__ __forceinline__ bool lean_in_range(float x)   // positive floats order like their bit patterns; NaN/inf/0/denormals fall outside
+{
+    return (__builtin_bit_cast(uint32_t, x) - __builtin_bit_cast(uint32_t, kExactLo)) <=
+           (__builtin_bit_cast(uint32_t, kExactHi) - __builtin_bit_cast(uint32_t, kExactLo));
+}
+__device__ __forceinline__ V3 normalize3_lean(V3 a, bool &inRange)
+{
+    const float s = a.x * a.x + a.y * a.y + a.z * a.z;
+    inRange = lean_in_range(s);                 // then sqrt(s) lies in [1e-15, 1e15], inside the reciprocal's range
+    const float t = rcp_rn_lean(sqrt_rn_lean(s));
+    return V3{a.x * t, a.y * t, a.z * t};
+}
+
 template <int NS>
-__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool alive0)
+__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool alive0, bool &outOfRange)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
-    bool alive = alive0, tirSeen = false, anyAlive = true;
+    bool alive = alive0, tirSeen = false, anyAlive = true, oor = false;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;
         if (!anyAlive) continue;
         const Surface &S = T.surf[i];
-        V3 u = normalize3(d);
+        bool r0, r1, r2, r3;
+        V3 u = normalize3_lean(d, r0);
         V3 L{0.0f - o.x, 0.0f - o.y, S.center - o.z};
         float tca = dot3(L, u);
         float d2 = dot3(L, L) - (tca * tca);
-        float thc = sqrtf(fabsf(S.radius2 - d2));
+        const float w = fabsf(S.radius2 - d2);
+        r1 = lean_in_range(w);
+        float thc = sqrt_rn_lean(w);
         float t = tca + thc * S.sign;
         V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
         float h2 = hit.x * hit.x + hit.y * hit.y;
         const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
-        V3 nrm = normalize3(V3{0.0f - hit.x, 0.0f - hit.y, S.center - hit.z});
+        V3 nrm = normalize3_lean(V3{0.0f - hit.x, 0.0f - hit.y, S.center - hit.z}, r2);
         nrm = V3{nrm.x * S.sign, nrm.y * S.sign, nrm.z * S.sign};
         o = hit;
-        V3 N = normalize3(nrm);
+        V3 N = normalize3_lean(nrm, r3);
+        oor |= alive & !(r0 & r1 & r2 & r3);   // a lane still alive HERE consumed these roots
         float c1 = -dot3(u, N);
         float cs2 = static_cast<float>(static_cast<double>(S.eta * S.eta) * (1.0 - static_cast<double>(c1 * c1)));
         const bool tirHere = (S.tirPossible != 0u) & (cs2 > 1.0f);
@@ -86,6 +110,7 @@ __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o
         d = V3{u.x * S.eta + N.x * k, u.y * S.eta + N.y * k, u.z * S.eta + N.z * k};
     }
     tirCount += tirSeen ? 1u : 0u;
+    outOfRange = oor;
     return alive;
 }
 

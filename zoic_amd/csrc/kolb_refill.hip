@@ -209,7 +209,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                 tries = 0; lutMiss = 0; dead = false;
                 if (T.useLUT) {            // zoic.cpp:1891-1911: per-sample constants of the exit-pupil transform
                     float dist;
-                    if constexpr (STRICT) dist = fabsf(sqrtf(o0x * o0x + o0y * o0y));
+                    if constexpr (STRICT) dist = fabsf(ZOIC_SQRT_RN(o0x * o0x + o0y * o0y));
                     else dist = fsqrt_fast(o0x * o0x + o0y * o0y);
                     lutMiss = lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation) ? 0u : 1u;
                     // the only discontinuity of the lookup is the table's end (bin edges interpolate continuously)
@@ -326,7 +326,13 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
             if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
             uint32_t tirTry = 0;   // 0/1: this try ended in total internal reflection
             if constexpr (NS > 0) {
-                if constexpr (STRICT) ok = trace_lens_strict_pred<NS>(T, o, d, tirTry, cand);
+                if constexpr (STRICT) {
+                    bool oor = false;
+                    ok = trace_lens_strict_pred<NS>(T, o, d, tirTry, cand, oor);
+                    if (__builtin_expect(__ballot(cand && oor) != 0ull, 0)) {   // never seen: a root left the lean sequences' verified range
+                        if (cand && oor) { o = oStart; d = dStart; tirTry = 0; ok = trace_lens_strict(T, o, d, tirTry); }
+                    }
+                }
                 else if constexpr (GUARD) { bool u2 = false; ok = trace_lens_fast_pred<NS, true>(fsurf, o, d, tirTry, cand, &u2); unsure |= cand && u2; }
                 else ok = trace_lens_fast_pred<NS>(fsurf, o, d, tirTry, cand);
 #ifdef ZOIC_EXP_DOUBLE_TRACE

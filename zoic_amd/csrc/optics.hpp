@@ -11,6 +11,17 @@
 
 #include "tables.hpp"
 
+// Correctly rounded f32 sqrt and reciprocal of the STRICT arithmetic: on the device the lean sequences of exact_math.hpp
+// (exhaustively verified equal to IEEE sqrt / divide, guarded outside their range), on the host the C library / compiler.
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "exact_math.hpp"
+#define ZOIC_SQRT_RN(x) ::zoic::sqrt_rn(x)
+#define ZOIC_RCP_RN(x) ::zoic::rcp_rn(x)
+#else
+#define ZOIC_SQRT_RN(x) sqrtf(x)
+#define ZOIC_RCP_RN(x) (1.0f / (x))
+#endif
+
 #pragma STDC FP_CONTRACT OFF
 
 namespace zoic {
@@ -27,8 +38,8 @@ ZOIC_HD float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 ZOIC_HD V3 normalize3(V3 a)
 {
-    float t = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
-    if (t != 0.0f) t = 1.0f / t;
+    float t = ZOIC_SQRT_RN(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (t != 0.0f) t = ZOIC_RCP_RN(t);
     return V3{a.x * t, a.y * t, a.z * t};
 }
 
@@ -134,7 +145,7 @@ ZOIC_HD bool trace_lens_strict(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCo
         float tca = dot3(L, u);
         float d2 = dot3(L, L) - (tca * tca);
         if (d2 > S.radius2) return false;
-        float thc = sqrtf(fabsf(S.radius2 - d2));
+        float thc = ZOIC_SQRT_RN(fabsf(S.radius2 - d2));
         float t = tca + thc * S.sign;
         V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
         // housing / user aperture clip, zoic.cpp:1111-1117
@@ -168,7 +179,7 @@ ZOIC_HD bool interface0_clear_strict(const KolbTable &T, V3 o, V3 d)
     float tca = dot3(L, u);
     float d2 = dot3(L, L) - (tca * tca);
     if (d2 > S.radius2) return false;
-    float thc = sqrtf(fabsf(S.radius2 - d2));
+    float thc = ZOIC_SQRT_RN(fabsf(S.radius2 - d2));
     float t = tca + thc * S.sign;
     V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
     float h2 = hit.x * hit.x + hit.y * hit.y;
