@@ -14,6 +14,14 @@ __global__ void check(unsigned long long *bad, unsigned long long *badGuarded, i
     for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
         const float x = __builtin_bit_cast(float, static_cast<uint32_t>(b));
         float ref, raw, guarded;
+        if (which == 2) {   // f64 sqrt of |1 - cs2| for every float cs2: compare the f64 bits
+            const double sd = fabs(1.0 - static_cast<double>(x));
+            const double r64 = sqrt(sd), l64 = zoic::sqrt64_rn_lean(sd);
+            const bool inRange = sd == 0.0 || (sd >= zoic::kExactLo64 && sd <= zoic::kExactHi64);
+            const bool same = (r64 != r64) ? (l64 != l64) : (__builtin_bit_cast(uint64_t, r64) == __builtin_bit_cast(uint64_t, l64));
+            if (!same) { ++nb; if (inRange) ++ng; }
+            continue;
+        }
         if (which == 0) { ref = static_cast<float>(sqrt(static_cast<double>(x))); raw = zoic::sqrt_rn_lean(x); guarded = zoic::sqrt_rn(x); }
         else { ref = static_cast<float>(1.0 / static_cast<double>(x)); raw = zoic::rcp_rn_lean(x); guarded = zoic::rcp_rn(x); }
         const uint32_t rb = __builtin_bit_cast(uint32_t, ref), cb = __builtin_bit_cast(uint32_t, raw), gb = __builtin_bit_cast(uint32_t, guarded);
@@ -29,12 +37,14 @@ int main()
 {
     unsigned long long *d, h[2];
     hipMalloc(&d, 16);
-    for (int which = 0; which < 2; ++which) {
+    int rc = 0;
+    for (int which = 0; which < 3; ++which) {
         hipMemset(d, 0, 16);
         hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, d, d + 1, which);
         hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
-        std::printf("%s: lean sequence wrong on %llu of 2^32 inputs (outside its stated range); guarded function wrong on %llu\n",
-                    which == 0 ? "sqrt" : "rcp ", h[0], h[1]);
+        std::printf("%s: lean sequence wrong on %llu of 2^32 inputs (outside its stated range); inside the range / guarded: wrong on %llu\n",
+                    which == 0 ? "sqrt f32      " : (which == 1 ? "rcp f32       " : "sqrt64|1-cs2| "), h[0], h[1]);
+        rc |= (h[1] != 0);
     }
-    return (h[1] != 0);
+    return rc;
 }

@@ -45,6 +45,27 @@ __device__ __forceinline__ float rcp_rn(float x)
     return 1.0f / x;
 }
 
+// sqrt(|1 - cs2|) in f64 for a FLOAT cs2 (calculateTransmissionVector, zoic.cpp:1023: `std::sqrt(std::abs(1.0 - cs2))`):
+// the operand is a function of one float, so the whole domain is 2^32 values and tools/ubench/exact_math_check.hip compares
+// this sequence with the correctly rounded f64 square root on every one of them.  It is hipcc's own Newton scheme on
+// v_rsq_f64 without the denormal scaling (v_ldexp_f64 x2, class test, selects): |1 - cs2| is 0 or >= 2^-24, never denormal.
+// valid for s == 0 or kExactLo64 <= s <= kExactHi64 (s = |1 - cs2|)
+constexpr double kExactLo64 = 1.0e-30, kExactHi64 = 1.0e30;
+__device__ __forceinline__ double sqrt64_rn_lean(double s)
+{
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, s);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, s);
+    g = __builtin_fma(d, h, g);
+    return s == 0.0 ? 0.0 : g;
+}
+
 }  // namespace zoic
 
 #pragma clang fp contract(off)

@@ -106,7 +106,9 @@ __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o
         const bool tirHere = (S.tirPossible != 0u) & (cs2 > 1.0f);
         tirSeen |= alive & !clipped & tirHere;
         alive &= !clipped & !tirHere;
-        float k = static_cast<float>(static_cast<double>(S.eta * c1) - sqrt(fabs(1.0 - static_cast<double>(cs2))));
+        // f64 sqrt of |1 - cs2| through the lean sequence (verified on every float cs2 with |1 - cs2| == 0 or in [1e-30, 1e30])
+        oor |= alive & !(fabsf(cs2) <= 1.0e30f);
+        float k = static_cast<float>(static_cast<double>(S.eta * c1) - sqrt64_rn_lean(fabs(1.0 - static_cast<double>(cs2))));
         d = V3{u.x * S.eta + N.x * k, u.y * S.eta + N.y * k, u.z * S.eta + N.z * k};
     }
     tirCount += tirSeen ? 1u : 0u;
