@@ -74,6 +74,24 @@ __device__ __forceinline__ V3 normalize3_lean(V3 a, bool &inRange)
     return V3{a.x * t, a.y * t, a.z * t};
 }
 
+// interface0_clear_strict (optics.hpp) with the lean roots; `inRange` false: the caller repeats the test with the guarded ones
+__device__ __forceinline__ bool interface0_clear_strict_lean(const KolbTable &T, V3 o, V3 d, bool &inRange)
+{
+    const Surface S = T.surf[0];
+    bool r0;
+    V3 u = normalize3_lean(d, r0);
+    V3 L{0.0f - o.x, 0.0f - o.y, S.center - o.z};
+    float tca = dot3(L, u);
+    float d2 = dot3(L, L) - (tca * tca);
+    const float w = fabsf(S.radius2 - d2);
+    inRange = r0 & lean_in_range(w);
+    float thc = sqrt_rn_lean(w);
+    float t = tca + thc * S.sign;
+    V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
+    float h2 = hit.x * hit.x + hit.y * hit.y;
+    return !((d2 > S.radius2) | (h2 > S.housing2));
+}
+
 template <int NS>
 __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool alive0, bool &outOfRange)
 {

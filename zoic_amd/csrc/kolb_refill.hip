@@ -288,7 +288,11 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                     d = V3{rx - o.x, ry - o.y, T.dirZ};
                 }
                 bool pass0, near0 = false;
-                if constexpr (STRICT) pass0 = interface0_clear_strict(T, o, d);
+                if constexpr (STRICT) {
+                    bool inRange;
+                    pass0 = interface0_clear_strict_lean(T, o, d, inRange);
+                    if (__builtin_expect(!inRange, 0)) pass0 = interface0_clear_strict(T, o, d);   // never seen: guarded roots
+                }
                 else if constexpr (GUARD) pass0 = interface0_clear_fast_guard(load_surface<false>(fsurf, 0), o, d, near0);   // band 0 unless the rear interface is the stop
                 else pass0 = interface0_clear_fast(load_surface<false>(fsurf, 0), o, d);
 #ifdef ZOIC_EXP_DOUBLE_PRETEST
