@@ -101,6 +101,8 @@ __device__ __forceinline__ V kernarg_field()
 // ray (above bit 0 of lutMiss) and reach the counters only when the ray finishes in this kernel.
 // (A third role -- handing "search-heavy" rays, still without a candidate after a few draws, to a kernel where every lane
 // is a searcher -- was built on the same lists and measured twice: it loses 10-40 %; removed.)
+constexpr uint32_t kRetryDeadBit = 0x40000000u;   // lutMiss: bit 0 LUT miss, bits 1.. the ray's TIR tally, bit 30 retry-dead
+
 template <bool STRICT, int NS, bool GUARD, bool LISTED>
 __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
                                                  uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching)
@@ -231,6 +233,17 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                         }
                     }
                 }
+                if (T.useLUT && T.retryOn && !dead) {
+                    // retry-dead test (tables.hpp): can ANY retry of this ray reach the rear element?  The retries sample
+                    // the disk of radius maxScale * |lens sample|max around the LUT centroid translated in BOTH components
+                    // and rotated by the ray's (parabola) cos/sin; 1 % + 1e-4 of margin dwarfs every rounding involved.
+                    const float k = T.useImage ? 1.4158f : 1.0023f;   // |lens sample| <= sqrt(2) (image) / 1.0011 (disk), x the rotation's 1.0011
+                    const float ccx = translation * (cs - sn) - o0x * T.retryK1, ccy = translation * (sn + cs) - o0y * T.retryK1;
+                    float dist2;
+                    if constexpr (STRICT) dist2 = sqrtf(o0x * o0x + o0y * o0y); else dist2 = fsqrt_fast(o0x * o0x + o0y * o0y);
+                    const float reach = (T.retryRho0 + dist2 * T.retrySpread + fabsf(maxScale) * k) * 1.01f + 1.0e-4f;
+                    if (ccx * ccx + ccy * ccy > reach * reach) lutMiss |= kRetryDeadBit;
+                }
                 active = true; fresh = true;
             }
             next += (nfree < avail) ? nfree : avail;
@@ -260,6 +273,19 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
                         const uint4 *states = ZOIC_KARG(rngStates);
                         if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
                         else rng = rng_for_ray(kernarg_field<uint32_t, offsetof(RefillArgs, T) + offsetof(KolbTable, seed)>(), ZOIC_KARG(rayBase) + idx);
+                    }
+                    if ((lutMiss & kRetryDeadBit) != 0u) {
+                        // every remaining retry dies at interface 0 (see the refill): step the stream over all but the
+                        // last one -- whose untouched (o, d) is the ray's final state (zoic.cpp:1951-1961) -- without
+                        // evaluating them.  A draw of exactly (0.5, 0.5) gives a NaN lens sample, which PASSES the
+                        // reference's comparisons: such a draw (probability 2e-15) is left to the normal path.
+                        while (tries < static_cast<uint32_t>(kMaxTries)) {
+                            Rng peek = rng;
+                            const uint32_t a = xor128(peek), b = xor128(peek);
+                            if (((a - 0x7fffffc0u) <= 0xc0u) & ((b - 0x7fffffc0u) <= 0xc0u)) break;
+                            rng = peek;
+                            ++tries;
+                        }
                     }
                     u = rng_unit(xor128(rng));
                     v = rng_unit(xor128(rng));
@@ -380,7 +406,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
         if constexpr (DEFER) {
             // stage the dropped rays' indices, add the finished rays' TIR tallies (LDS traffic only)
             const bool drop = active && unsure;
-            const uint32_t tally = finished ? (lutMiss >> 1) : 0u;
+            const uint32_t tally = finished ? ((lutMiss & ~kRetryDeadBit) >> 1) : 0u;
             if (__ballot(drop || tally != 0u) != 0ull) {
                 const unsigned long long dropMask = __ballot(drop);
                 const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dropMask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dropMask), 0u));

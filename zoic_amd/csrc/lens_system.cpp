@@ -383,6 +383,28 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
         t.lutMaxScale[i] = (sx >= sy) ? sx : sy;
         t.lutCentroidX[i] = cx;
     }
+    // Retry-dead shortcut.  A try starts at o = (ox, oy, originShift) with d = (lens - o.xy, dirZ); it survives interface 0
+    // only if it meets the rear sphere at a point H with |H.xy| <= a (housing radius) -- a point of the cap between the
+    // vertex plane z_v and the rim plane z_rim.  With H = o + lambda * d, lambda = (H.z - o.z) / dirZ lies in
+    // [lambda_lo, lambda_hi], and lens = o.xy * (1 - 1/lambda) + H.xy / lambda: every lens point that can pass lies within
+    // a/lambda_lo + |o.xy| * (1/lambda_lo - 1/lambda_hi)/2 of o.xy * (1 - mean(1/lambda)).  The kernel compares that disk
+    // with the disk the retries sample (centre: the doubly translated LUT centroid, radius: maxScale) with a 1 % margin.
+    t.retryOn = 0; t.retryK1 = t.retryRho0 = t.retrySpread = 0.0f;
+    if (hasLUT && !rows.empty()) {
+        const double R = rows[0].radius, a = std::sqrt(static_cast<double>(t.surf[0].housing2)), dirZ = t.dirZ, oz = originShift;
+        if (a < std::fabs(R) && dirZ > 0.0) {
+            const double sag = std::fabs(R) - std::sqrt(R * R - a * a);
+            const double zv = static_cast<double>(rows[0].center) + R, zrim = zv - (R < 0.0 ? -1.0 : 1.0) * sag;
+            const double l1 = (zv - oz) / dirZ, l2 = (zrim - oz) / dirZ;
+            const double lo = std::min(l1, l2), hi = std::max(l1, l2);
+            if (lo > 1.0e-3 && std::isfinite(hi)) {
+                t.retryOn = 1;
+                t.retryK1 = static_cast<float>(1.0 - 0.5 * (1.0 / lo + 1.0 / hi));
+                t.retryRho0 = static_cast<float>(a / lo);
+                t.retrySpread = static_cast<float>(0.5 * (1.0 / lo - 1.0 / hi));
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ bokeh CDF

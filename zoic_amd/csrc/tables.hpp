@@ -71,6 +71,14 @@ struct KolbTable {
     int32_t exposureOn;
     uint32_t seed;
     float bandLutBin;     // decision-safe FAST: |dist*8 - round(dist*8)| below this leaves the LUT bin to STRICT
+    // "Retry-dead" shortcut (kolb_refill.hip): the reference translates a RETRY's lens sample by the LUT centroid in BOTH
+    // components (zoic.cpp:1933; the first try in x only, :1914), which moves the retry disk off the rear element for every
+    // pixel far enough from the axis -- all 26 retries then die at interface 0.  These constants bound, per ray, the region
+    // of the lens-sample plane from which a ray can reach the rear element's cap (host: lens_system.cpp fill_table).
+    int32_t retryOn;      // 0: geometry outside the shortcut's assumptions -> never taken
+    float retryK1;        // centre of that region = o.xy * retryK1
+    float retryRho0;      // its radius = retryRho0 + |o.xy| * retrySpread
+    float retrySpread;
     Surface surf[kMaxSurfaces];
     FastSurface fsurf[kMaxSurfaces];
     float lutMaxScale[kLutEntries];  // boundingBox2d::getMaxScale per LUT entry (zoic.cpp:503-517)
