@@ -123,7 +123,7 @@ struct LaunchSlot {
     hipEvent_t done = nullptr;
     bool recorded = false;
     hipStream_t lastStream = nullptr;   // a launch on the same stream is ordered behind the previous one: no event wait needed
-    DeviceBuffer<uint32_t> redo;        // decision-safe FAST: the STRICT kernel's work list, one dword per sample of the launch
+    DeviceBuffer<uint32_t> redo;        // the Kolb launch's scratch (kolb_scratch_dwords): work list of decision-safe FAST, finish kernel's byte map
 };
 
 // Private scratch of ONE host-buffer call in flight: leased from the camera's pool for the duration of the call.
@@ -505,7 +505,9 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
     if (model != ZOIC_RAYTRACED && model != ZOIC_THINLENS)
         return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
     const int mode = cam->precision == ZOIC_PRECISION_STRICT ? 0 : (cam->precision == ZOIC_PRECISION_FAST ? 1 : 2);
-    const bool needList = model == ZOIC_RAYTRACED && mode == 1;   // decision-safe FAST: the STRICT kernel's work list (kolb_refill.hip)
+    // the Kolb launch's scratch (kernels.hpp): decision-safe FAST's work list, the finish kernel's byte map
+    const size_t listEntries = model == ZOIC_RAYTRACED ? kolb_scratch_dwords(cam->kolb, n, mode) : 0;
+    const bool needList = listEntries != 0;
     // Slot choice.  A caller that keeps launching on one stream keeps ONE slot (its launches are ordered anyway, and the
     // slot's work-list buffer is allocated once); otherwise the first idle slot; with all 64 busy, the next in turn,
     // behind its previous user's completion event.
@@ -525,9 +527,8 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
     }
     (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error of this call
     if (slot->recorded && slot->lastStream != stream) ZOIC_HIP(hipStreamWaitEvent(stream, slot->done, 0));
-    const size_t listEntries = static_cast<size_t>(n < (1ull << 31) ? n : (1ull << 31));
     if (needList && slot->redo.cap < listEntries) {
-        // growing the list frees the old one: the slot's previous launch must be over (rare: first use / a larger batch)
+        // growing the scratch frees the old one: the slot's previous launch must be over (rare: first use / a larger batch)
         if (slot->recorded) ZOIC_HIP(hipEventSynchronize(slot->done));
         ZOIC_HIP(slot->redo.reserve(listEntries));
     }

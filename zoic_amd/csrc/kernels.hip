@@ -268,7 +268,7 @@ int launch_kolb_fast(const KolbTable &table, const BokehTables &bokeh, const flo
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, void *stream);
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                        uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                       int mode, uint32_t *d_redoList, void *stream);
+                       int mode, uint32_t *d_scratch, void *stream);
 
 // ZOIC_KOLB_VARIANT = refill (persistent lane refill, default) | simple (one sample per lane, retry loop in the lane:
 // the A/B baseline of DESIGN.md's ladder).
@@ -281,10 +281,10 @@ static bool use_simple_variant() { return std::strcmp(kolb_variant(), "simple") 
 
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                     int mode, uint32_t *d_redoList, void *stream)
+                     int mode, uint32_t *d_scratch, void *stream)
 {
     if (n == 0) return 0;
-    if (!use_simple_variant()) return launch_kolb_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_redoList, stream);
+    if (!use_simple_variant()) return launch_kolb_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
     if (mode != 0) return launch_kolb_fast(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, stream);
     hipLaunchKernelGGL(kolb_rays_strict_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,
                        reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,

@@ -390,7 +390,8 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
     // a/lambda_lo + |o.xy| * (1/lambda_lo - 1/lambda_hi)/2 of o.xy * (1 - mean(1/lambda)).  The kernel compares that disk
     // with the disk the retries sample (centre: the doubly translated LUT centroid, radius: maxScale) with a 1 % margin.
     t.retryOn = 0; t.retryK1 = t.retryRho0 = t.retrySpread = 0.0f;
-    if (hasLUT && !rows.empty()) {
+    static const bool retryOff = [] { const char *e = std::getenv("ZOIC_RETRY_DEAD"); return e && e[0] == '0'; }();   // A/B: no ray is ever classified
+    if (hasLUT && !rows.empty() && !retryOff) {
         const double R = rows[0].radius, a = std::sqrt(static_cast<double>(t.surf[0].housing2)), dirZ = t.dirZ, oz = originShift;
         if (a < std::fabs(R) && dirZ > 0.0) {
             const double sag = std::fabs(R) - std::sqrt(R * R - a * a);
