@@ -4,6 +4,7 @@
 // reference because the tables it emits steer every accept/reject decision of the hot path.  Strict IEEE:
 // compiled with -ffp-contract=off, f64 intermediates where zoic.cpp has them.
 #include "lens_system.hpp"
+#include "optics.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -405,6 +406,27 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
                 t.retrySpread = static_cast<float>(0.5 * (1.0 / lo - 1.0 / hi));
             }
         }
+    }
+    // The shortcut has a price -- a byte map to clear, a finish kernel to launch, staging in the pass loop -- that a camera
+    // with a handful of such pixels should not pay (the double Gauss at 50 mm: +1.5 % of the launch for 0.1 % of the rays).
+    // Estimate the share of the sensor square the per-ray test (kolb_refill_body.hpp setup_ray) classifies and keep the
+    // shortcut for cameras where that is a real part of the frame; without it the same rays simply draw their 26 samples.
+    if (t.retryOn) {
+        const int grid = 64;
+        int hits = 0;
+        for (int iy = 0; iy < grid; ++iy)
+            for (int ix = 0; ix < grid; ++ix) {
+                const float ox = (static_cast<float>(ix) + 0.5f) / grid * 2.0f - 1.0f, oy = (static_cast<float>(iy) + 0.5f) / grid * 2.0f - 1.0f;
+                const float o0x = ox * t.halfSensor, o0y = oy * t.halfSensor, dist = std::sqrt(o0x * o0x + o0y * o0y);
+                float maxScale = 0.0f, translation = 0.0f;
+                if (!lut_lookup(t, dist, maxScale, translation) || (maxScale == 0.0f && translation == 0.0f)) continue;   // dead pixels have their own shortcut
+                const float theta = std::atan2(o0y, o0x), sn = std::sin(theta), cs = std::cos(theta);
+                const float ccx = translation * (cs - sn) - o0x * t.retryK1, ccy = translation * (sn + cs) - o0y * t.retryK1;
+                const float reach = (t.retryRho0 + dist * t.retrySpread + std::fabs(maxScale) * 1.4158f) * 1.01f + 1.0e-4f;
+                if (ccx * ccx + ccy * ccy > reach * reach) ++hits;
+            }
+        static const double minShare = [] { const char *e = std::getenv("ZOIC_RETRY_DEAD_MIN_SHARE"); return e ? std::atof(e) : 0.02; }();
+        if (hits < minShare * grid * grid) t.retryOn = 0;
     }
 }
 
