@@ -15,7 +15,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzoic_amd.so")
 SOURCES = ["capi.cpp", "lens_system.cpp", "kernels.hip", "kolb_fast.hip", "kolb_refill.hip", "kolb_refill_dead.hip", "thin_refill.hip", "bokeh_cdf.hip"]
-HEADERS = ["tables.hpp", "optics.hpp", "fast_optics.hpp", "device_search.hpp", "ray_store.hpp", "kolb_device.hpp", "work_cursor.hpp", "lens_system.hpp", "kernels.hpp", os.path.join(ROOT, "include", "zoic_amd.h")]
+# every header of csrc/ is a dependency of every object (a hand-kept list went stale twice: exact_math.hpp, kolb_refill_body.hpp)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(ROOT, "include", "zoic_amd.h")]
 
 # -ffp-contract=off: strict kernels and the host precompute must round exactly like the CPU oracle;
 # the fast kernel re-enables contraction locally with a pragma.  -fno-slp-vectorize: packing scalar f32 math into
