@@ -80,6 +80,48 @@ def test_strict_replays_the_sequential_reference_stream(gpu, oracle_lib):
     assert 0.1 < float((ref["flags"] & 1).mean()) < 0.9
 
 
+def test_retry_dead_ray_whose_draw_is_the_disk_centre(gpu, oracle_lib):
+    """Retry-dead rays are completed by the finish kernel, which only steps their retry stream -- unless a
+    draw is exactly (0.5, 0.5): the concentric-disk sample is then NaN, a NaN ray passes every comparison of the reference's
+    trace, and the ray is a SUCCESS with NaN origin / direction at that try.  Probability 2e-15 per draw, so it is staged:
+    streams built to produce 0x80000000 twice at their first draw (xor128 run backwards), and at their fifth."""
+    from zoic_amd import PRECISION_FAST, PRECISION_STRICT
+    cam, oc = make_pair(oracle_lib, "C2")
+    n = 1 << 15
+    s, base = slab("C2", n, 0.02)                      # top rows of the TESSAR frame: off-axis, retries cannot reach the rear element
+    states = ray_rng_states(n, 1, base)
+    plain = oc.create_rays(s, rng_states=states)
+    dead = np.flatnonzero((plain["weight"] == 0) & (((plain["flags"] >> 1) & 31) == 26))
+    assert dead.size > 2000
+    first = np.array([0, 0x04809010, 0x12345678, 0x80001000], np.uint32)   # outputs 1, 2 = 0x80000000, 0x80000000
+
+    def step_back(st):                                  # the xorshift128 state one draw earlier
+        x1, y1, z1, w1 = (int(v) for v in st)
+        w0 = z1
+        u = w1 ^ w0 ^ (w0 >> 19)                       # = t ^ (t >> 8)
+        t = u ^ (u >> 8) ^ (u >> 16) ^ (u >> 24)
+        x0 = (t ^ (t << 11) ^ (t << 22)) & 0xffffffff
+        return np.array([x0, x1, y1, w0], np.uint32)
+    fifth = first
+    for _ in range(8):                                  # four draws = eight numbers earlier
+        fifth = step_back(fifth)
+    states[dead[0::9]] = first
+    states[dead[4::9]] = fifth
+    ref = oc.create_rays(s, rng_states=states)
+    hit1, hit5 = dead[0::9], dead[4::9]
+    assert (ref["weight"][hit1] == 1).all() and (((ref["flags"][hit1] >> 1) & 31) == 1).all() and np.isnan(ref["planes"][3:6, hit1]).all()
+    assert (ref["weight"][hit5] == 1).all() and (((ref["flags"][hit5] >> 1) & 31) == 5).all()
+    for mode in (PRECISION_STRICT, PRECISION_FAST):
+        cam.set_precision(mode)
+        got = cam.create_rays(s, rng_states=states)
+        assert np.array_equal(got["flags"], ref["flags"])
+        assert np.array_equal(got["weight"], ref["weight"])
+        g, r = got["planes"], ref["planes"]
+        assert np.array_equal(np.isnan(g), np.isnan(r))
+        if mode == PRECISION_STRICT:
+            assert ((bits(g) == bits(r)) | np.isnan(r)).all()
+
+
 @pytest.mark.parametrize("kw", [
     dict(kolbSamplingLUT=False),                                        # naive sampling over the rear element, zoic.cpp:1873-1888
     dict(exposureControl=1.5), dict(exposureControl=-2.0),              # zoic.cpp:1981-1987
