@@ -20,13 +20,15 @@ constexpr uint32_t kMaxChunkRays = 1024;   // 16 passes of fresh work
 
 struct WorkGrain { uint32_t chunkRays, chunksPerPart; };
 
-// chunk size for a batch of m samples: 64-sample tiles on small batches, 256 from 4 M samples (below that a wave
-// changes chunk -- an exposed atomic + window fetch -- every few passes), 512 on a 4K x 16spp frame, 1024 at most.
-// ZOIC_CHUNK_RAYS overrides the rule (experiments).
-inline WorkGrain work_grain(uint64_t m)
+// chunk size for a batch of m samples: 64-sample tiles on small batches; from 4 M samples at least `floorRays` (a wave
+// changes chunk -- an exposed atomic + window fetch -- every few passes otherwise): 512 for the FAST Kolb kernels (TESSAR
+// 1080p x 8, 16.6 M rays: 256 -> 21.5, 384 -> 22.4, 512 -> 23.1, 768 -> 21.9, 1024 -> 21.0 Grays/s unchecked), 256 for the
+// STRICT ones, whose passes are 2.5x longer (14.9 at 256, 14.5 at 512) and for the thin lens; 512 on a 4K x 16spp frame by
+// the claim budget, 1024 at most.  ZOIC_CHUNK_RAYS overrides the rule (experiments).
+inline WorkGrain work_grain(uint64_t m, uint32_t floorRays = 256)
 {
     uint64_t chunk = (m / (32768ull * kCursorParts) + 63) / 64 * 64;
-    if (chunk < 256 && m >= (4ull << 20)) chunk = 256;
+    if (chunk < floorRays && m >= (4ull << 20)) chunk = floorRays;
     static const uint32_t chunkOverride = [] { const char *e = std::getenv("ZOIC_CHUNK_RAYS"); return e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }();
     WorkGrain g;
     g.chunkRays = chunkOverride ? chunkOverride : static_cast<uint32_t>(chunk < 64 ? 64 : (chunk > kMaxChunkRays ? kMaxChunkRays : chunk));
