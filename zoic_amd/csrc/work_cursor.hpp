@@ -48,7 +48,8 @@ inline unsigned persistent_grid(uint64_t m, unsigned wavesPerBlock)
 {
     const uint64_t tiles = (m + 63) / 64;
     const uint64_t wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
-    return static_cast<unsigned>(wantBlocks < 2048 ? (wantBlocks ? wantBlocks : 1) : 2048);
+    static const uint64_t cap = [] { const char *e = std::getenv("ZOIC_GRID_BLOCKS"); return e ? static_cast<uint64_t>(std::atol(e)) : uint64_t(2048); }();   // experiments
+    return static_cast<unsigned>(wantBlocks < cap ? (wantBlocks ? wantBlocks : 1) : cap);
 }
 
 #if defined(__HIPCC__)
