@@ -42,13 +42,26 @@ inline hipError_t reset_work_cursors(unsigned int *d_workCursor, hipStream_t st)
     return hipMemsetAsync(d_workCursor, 0, kCursorParts * kCursorPartStride * sizeof(unsigned int), st);   // same stream as the kernel: ordered
 }
 
-// persistent grid: enough 256-lane workgroups to fill every wave slot of 256 CUs; late or surplus workgroups find the
-// cursors exhausted and retire at once, so residency need not be known exactly
+// persistent grid.  Large batches: enough 256-lane workgroups to fill every wave slot of 256 CUs (late or surplus workgroups
+// find the cursors exhausted and retire at once, so residency need not be known exactly).  Small batches: sqrt(m) / 2
+// workgroups -- every wave pays its start (LDS tables, first claim, first window: three dependent round trips) and its
+// tail (the last rays' remaining tries at a few lanes per pass) once, so fewer waves with more rays each win until the
+// chip runs short of waves to hide latency with.  Measured optimum on TESSAR unchecked / double Gauss decision-safe /
+// TESSAR strict alike (tools/exp_grid.py): 256 K rays -> 256 workgroups, 1 M -> 512, 4 M -> 1024, 16 M -> 2048; against
+// "one wave per 64 rays, 2048 at most": 1 M rays 293 -> 167 us, 2 M 337 -> 235, 4 M 303 -> 272 (TESSAR unchecked).
+// ZOIC_GRID_BLOCKS overrides the rule (experiments).
 inline unsigned persistent_grid(uint64_t m, unsigned wavesPerBlock)
 {
     const uint64_t tiles = (m + 63) / 64;
     const uint64_t wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
-    static const uint64_t cap = [] { const char *e = std::getenv("ZOIC_GRID_BLOCKS"); return e ? static_cast<uint64_t>(std::atol(e)) : uint64_t(2048); }();   // experiments
+    static const uint64_t capOverride = [] { const char *e = std::getenv("ZOIC_GRID_BLOCKS"); return e ? static_cast<uint64_t>(std::atol(e)) : uint64_t(0); }();
+    uint64_t cap = 2048;
+    if (capOverride) cap = capOverride;
+    else {
+        uint64_t r = 1;
+        while (4 * r * r < m && r < 2048) ++r;   // ceil(sqrt(m) / 2)
+        cap = r < 2048 ? r : 2048;
+    }
     return static_cast<unsigned>(wantBlocks < cap ? (wantBlocks ? wantBlocks : 1) : cap);
 }
 
