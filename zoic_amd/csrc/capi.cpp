@@ -637,8 +637,8 @@ zoic_status zoic_camera_create(int device, zoic_camera **out)
     cam->lutOnHost = env && env[0] == '1';
     cam->tidStates.reset(new std::atomic<TidState *>[kTidStates]);
     for (unsigned i = 0; i < kTidStates; ++i) cam->tidStates[i].store(nullptr, std::memory_order_relaxed);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&cam->dCounters), sizeof(DeviceCounters));
-    if (e == hipSuccess) e = hipMemset(cam->dCounters, 0, sizeof(DeviceCounters));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&cam->dCounters), kCounterSets * sizeof(DeviceCounters));   // kernels.hpp: one set per line
+    if (e == hipSuccess) e = hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), kLaunchSlots * kCursorStride * sizeof(unsigned int));
     for (unsigned i = 0; e == hipSuccess && i < kLaunchSlots; ++i) {
         cam->slots[i].cursor = cam->dWorkCursor + i * kCursorStride;
@@ -795,8 +795,11 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
             if (zoic_status s = lens_error_status(le)) return s;
             if (!g_lastError.empty()) return ZOIC_ERR_HIP;
             // counters restart with the lens (zoic.cpp:1626-1628); the precompute's TIR bumps stay in (zoic.cpp:1135 ff.)
-            DeviceCounters zero{0, 0, cam->lens.precomputeTIR};
-            if (onDevice) ZOIC_HIP(hipMemcpy(cam->dCounters, &zero, sizeof(zero), hipMemcpyHostToDevice));
+            DeviceCounters zero{0, 0, cam->lens.precomputeTIR, {}};
+            if (onDevice) {
+                ZOIC_HIP(hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters)));
+                ZOIC_HIP(hipMemcpy(cam->dCounters, &zero, sizeof(zero), hipMemcpyHostToDevice));   // set 0 carries the precompute's bumps
+            }
             cam->lensDirty = false;
         }
         break;
@@ -1053,8 +1056,10 @@ zoic_status zoic_camera_get_counters(zoic_camera *cam, zoic_counters *out)
     DeviceGuard guard(cam->device);
     ZOIC_HIP(guard.error());
     ZOIC_HIP(hipDeviceSynchronize());   // every stream of the device: launches of all threads are counted
+    std::vector<DeviceCounters> sets(kCounterSets);
+    ZOIC_HIP(hipMemcpy(sets.data(), cam->dCounters, kCounterSets * sizeof(DeviceCounters), hipMemcpyDeviceToHost));
     DeviceCounters c{};
-    ZOIC_HIP(hipMemcpy(&c, cam->dCounters, sizeof(c), hipMemcpyDeviceToHost));
+    for (const DeviceCounters &s : sets) { c.succes += s.succes; c.vignetted += s.vignetted; c.tir += s.tir; }
     out->succesRays = c.succes; out->vignettedRays = c.vignetted; out->totalInternalReflection = c.tir;
     return ZOIC_OK;
 }
@@ -1066,7 +1071,7 @@ zoic_status zoic_camera_reset_counters(zoic_camera *cam)
     DeviceGuard guard(cam->device);
     ZOIC_HIP(guard.error());
     ZOIC_HIP(hipDeviceSynchronize());
-    ZOIC_HIP(hipMemset(cam->dCounters, 0, sizeof(DeviceCounters)));
+    ZOIC_HIP(hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters)));
     return ZOIC_OK;
 }
 

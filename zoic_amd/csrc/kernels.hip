@@ -35,6 +35,7 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ void flush_counters(DeviceCounters *c, uint32_t succ, uint32_t vign, uint32_t tir)
 {
     if (!c) return;
+    c = counter_set(c);
     __shared__ uint32_t part[3][kBlock / 64];
     for (int off = 32; off > 0; off >>= 1) {
         succ += __shfl_down(succ, off, 64);

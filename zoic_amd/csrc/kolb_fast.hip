@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kBlockF) void kolb_rays_fast_kernel(const KolbTable
     if (counters && threadIdx.x < 3) {
         unsigned long long sum = 0;
         for (int w = 0; w < kBlockF / 64; ++w) sum += part[threadIdx.x][w];
-        unsigned long long *dst = threadIdx.x == 0 ? &counters->succes : (threadIdx.x == 1 ? &counters->vignetted : &counters->tir);
+        DeviceCounters *cs = counter_set(counters);
+        unsigned long long *dst = threadIdx.x == 0 ? &cs->succes : (threadIdx.x == 1 ? &cs->vignetted : &cs->tir);
         if (sum) atomicAdd(dst, sum);
     }
 }

@@ -553,7 +553,7 @@ __device__ __forceinline__ void kolb_refill_body(const KolbTable &T, const Bokeh
     ZOIC_RT_FLUSH
     ZOIC_PS_FLUSH
     // ---- counters: the wave totals, one atomic per counter per wave ---------------------------------------------
-    DeviceCounters *counters = ZOIC_KARG(counters);
+    DeviceCounters *counters = counter_set(ZOIC_KARG(counters));
     if (counters) {
         if (lane == 0) {
             if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
@@ -612,8 +612,9 @@ __global__ __launch_bounds__(kRefillBlock) void kolb_finish_kernel(const KolbTab
         __builtin_amdgcn_wave_barrier();
     }
     if (counters && lane == 0) {
-        if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
-        if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
+        DeviceCounters *cs = counter_set(counters);
+        if (succ) atomicAdd(&cs->succes, static_cast<unsigned long long>(succ));
+        if (vign) atomicAdd(&cs->vignetted, static_cast<unsigned long long>(vign));
     }
 }
 
@@ -645,6 +646,8 @@ int launch_kolb_refill_impl(const KolbTable &table, const BokehTables &bokeh, co
                             int mode, uint32_t *d_scratch, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    static const bool noCounters = std::getenv("ZOIC_EXP_NO_COUNTERS") != nullptr;   // experiment: what do the per-wave counter atomics cost?
+    if (noCounters) d_counters = nullptr;
     if ((mode == 1 || DEAD) && !d_scratch) return static_cast<int>(hipErrorInvalidValue);
     // one launch covers < 2^31 samples (32-bit ray offsets inside the kernel); larger batches are split
     constexpr uint64_t kMaxPerLaunch = 1ull << 31;
@@ -708,7 +711,8 @@ int launch_kolb_refill_impl(const KolbTable &table, const BokehTables &bokeh, co
         if (e != hipSuccess) return static_cast<int>(e);
         if constexpr (DEAD) {   // last: the rays the kernels above marked
             const uint32_t blocks = static_cast<uint32_t>((m + kFinishBlock - 1) / kFinishBlock);
-            const unsigned fgrid = (blocks + kWavesPerBlock - 1) / kWavesPerBlock < 2048u ? (blocks + kWavesPerBlock - 1) / kWavesPerBlock : 2048u;
+            static const unsigned fcap = [] { const char *e = std::getenv("ZOIC_FINISH_BLOCKS"); return e ? static_cast<unsigned>(std::atoi(e)) : 2048u; }();   // experiments
+            const unsigned fgrid = (blocks + kWavesPerBlock - 1) / kWavesPerBlock < fcap ? (blocks + kWavesPerBlock - 1) / kWavesPerBlock : fcap;
             const size_t fLds = static_cast<size_t>(ldsWords + kLutLdsWords) * sizeof(float) + kWavesPerBlock * kFinishBlock * sizeof(uint16_t);
             if (mode == 0) hipLaunchKernelGGL((kolb_finish_kernel<true>), dim3(fgrid), dim3(kRefillBlock), fLds, st, table, bokeh, sp, rp, rayBase + done,
                                               static_cast<uint32_t>(m), o, d_counters, ldsWords, deadMap);

@@ -170,8 +170,9 @@ __global__ __launch_bounds__(kThinBlock) void thin_refill_kernel(const ThinTable
     }
     if (parked) flush_parked_records(out, stage, stageIdx, lane);
     if (counters && lane == 0) {
-        if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
-        if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
+        DeviceCounters *cs = counter_set(counters);
+        if (succ) atomicAdd(&cs->succes, static_cast<unsigned long long>(succ));
+        if (vign) atomicAdd(&cs->vignetted, static_cast<unsigned long long>(vign));
     }
 }
 
