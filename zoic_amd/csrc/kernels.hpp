@@ -43,7 +43,10 @@ __device__ __forceinline__ DeviceCounters *counter_set(DeviceCounters *base)
 // d_workCursor: kCursorParts device words, kCursorPartStride dwords apart, the persistent kernel uses as its chunk cursors
 // (zeroed on the stream per launch).  One cursor per eighth of the batch: same-address atomics are served one per ~12 ns
 // by the L2, different addresses in parallel; a wave starts on its workgroup's home partition and moves on when it is empty.
-constexpr unsigned kCursorParts = 8;
+#ifndef ZOIC_CURSOR_PARTS
+#define ZOIC_CURSOR_PARTS 8
+#endif
+constexpr unsigned kCursorParts = ZOIC_CURSOR_PARTS;   // compile-time A/B: tools/build_variant.sh p4 -DZOIC_CURSOR_PARTS=4
 constexpr unsigned kCursorPartStride = 64;   // 256 bytes apart
 // The same 2 KB block also holds what the decision-safe FAST mode needs (kolb_refill.hip), each on its own 64-byte line;
 // the one memset per launch zeroes all of it.  Dword offsets into the block:
