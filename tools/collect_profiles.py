@@ -15,7 +15,7 @@ for f in sorted(glob.glob(src + "/pmc*/*/*_counter_collection.csv")):
                                            "Accum_VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp")})
 with open(dst + "/pmc_counters.csv", "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-out = subprocess.check_output([sys.executable, "tools/pmc_summary.py", src, str(nrays)] + (["thin_rays"] if "thin" in tag else []), text=True)
+out = subprocess.check_output([sys.executable, "tools/pmc_summary.py", src, str(nrays)] + (["thin_r"] if ("thin" in tag or key.startswith("C1")) else []), text=True)
 open(dst + "/summary.txt", "w").write(out)
 shutil.copy(src + "/summary.json", dst + "/summary.json")
 s = json.load(open(dst + "/summary.json"))
