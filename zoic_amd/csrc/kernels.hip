@@ -270,6 +270,9 @@ int launch_kolb_fast(const KolbTable &table, const BokehTables &bokeh, const flo
 int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                        uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                        int mode, uint32_t *d_scratch, void *stream);
+int launch_kolb_pool(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                     int mode, uint32_t *d_scratch, void *stream);
 
 // ZOIC_KOLB_VARIANT = refill (persistent lane refill, default) | simple (one sample per lane, retry loop in the lane:
 // the A/B baseline of DESIGN.md's ladder).
@@ -285,6 +288,8 @@ int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const flo
                      int mode, uint32_t *d_scratch, void *stream)
 {
     if (n == 0) return 0;
+    static const bool pool = std::strcmp(kolb_variant(), "pool") == 0;
+    if (pool) return launch_kolb_pool(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
     if (!use_simple_variant()) return launch_kolb_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
     if (mode != 0) return launch_kolb_fast(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, stream);
     hipLaunchKernelGGL(kolb_rays_strict_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,

@@ -1,0 +1,19 @@
+// kolb_pool.hip -- the Kolb launch of the batch + pool kernels (kolb_pool_body.hpp) and their instantiations for cameras
+// WITHOUT retry-dead rays (KolbTable::retryOn == 0: no LUT, or every retry can reach the rear element).
+#include "kolb_pool_body.hpp"
+
+namespace zoic {
+
+int launch_kolb_pool_dead(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                          uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                          int mode, uint32_t *d_scratch, void *stream);   // kolb_pool_dead.hip
+
+int launch_kolb_pool(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                     int mode, uint32_t *d_scratch, void *stream)
+{
+    if (table.retryOn) return launch_kolb_pool_dead(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
+    return launch_kolb_pool_impl<false>(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
+}
+
+}  // namespace zoic

@@ -1,0 +1,15 @@
+// kolb_pool_dead.hip -- the batch + pool Kolb kernels for cameras WITH retry-dead rays (KolbTable::retryOn: off-axis pixels
+// whose 26 retries all miss the rear element, tables.hpp): they complete those rays inside the kernel, 64 at a time.  A
+// translation unit of its own: the two sets of kernels compile side by side, and cameras without such rays carry none of it.
+#include "kolb_pool_body.hpp"
+
+namespace zoic {
+
+int launch_kolb_pool_dead(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
+                          uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                          int mode, uint32_t *d_scratch, void *stream)
+{
+    return launch_kolb_pool_impl<true>(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
+}
+
+}  // namespace zoic

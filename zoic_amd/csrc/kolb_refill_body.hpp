@@ -152,7 +152,9 @@ __device__ __forceinline__ RaySetup setup_ray(const KolbTable &T, const float2 *
                 const float k = T.useImage ? 1.4158f : 1.0023f;   // |lens sample| <= sqrt(2) (image) / 1.0011 (disk), x the rotation's 1.0011
                 const float ccx = r.translation * (r.cs - r.sn) - r.o0x * T.retryK1, ccy = r.translation * (r.sn + r.cs) - r.o0y * T.retryK1;
                 const float reach = (T.retryRho0 + dist * T.retrySpread + fabsf(r.maxScale) * k) * 1.01f + 1.0e-4f;
-                if (ccx * ccx + ccy * ccy > reach * reach) r.flags |= kRetryDeadBit;
+                // |d.xy| of any retry <= |rotated, translated lens point| + |o.xy|: below retryMaxD the opposite cap is out of reach
+                const float dxyMax = fabsf(r.maxScale) * k + fabsf(r.translation) * 1.4158f + dist;
+                if (ccx * ccx + ccy * ccy > reach * reach && dxyMax <= T.retryMaxD) r.flags |= kRetryDeadBit;
             }
         }
     }

@@ -390,7 +390,12 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
     // [lambda_lo, lambda_hi], and lens = o.xy * (1 - 1/lambda) + H.xy / lambda: every lens point that can pass lies within
     // a/lambda_lo + |o.xy| * (1/lambda_lo - 1/lambda_hi)/2 of o.xy * (1 - mean(1/lambda)).  The kernel compares that disk
     // with the disk the retries sample (centre: the doubly translated LUT centroid, radius: maxScale) with a 1 % margin.
-    t.retryOn = 0; t.retryK1 = t.retryRho0 = t.retrySpread = 0.0f;
+    // H must be THAT cap: raySphereIntersection takes one signed root (zoic.cpp:986) and never rejects t < 0, and the sphere
+    // has a second cap with |xy| <= a on its far side.  At a point of that cap the outward normal n has |n.xy| <= a/|R| and
+    // |n.z| >= sqrt(R^2 - a^2)/|R|; the root the reference takes is the ray's entry (R < 0) or exit (R > 0) point, which needs
+    // n.d < 0 resp. > 0 against the sign of n.z -- possible only for |d.xy| / dirZ > sqrt(R^2 - a^2) / a.  retryMaxD is that
+    // bound on |d.xy| (1 % margin); the per-ray test leaves rays that could exceed it to their 26 draws.
+    t.retryOn = 0; t.retryK1 = t.retryRho0 = t.retrySpread = t.retryMaxD = 0.0f;
     static const bool retryOff = [] { const char *e = std::getenv("ZOIC_RETRY_DEAD"); return e && e[0] == '0'; }();   // A/B: no ray is ever classified
     if (hasLUT && !rows.empty() && !retryOff) {
         const double R = rows[0].radius, a = std::sqrt(static_cast<double>(t.surf[0].housing2)), dirZ = t.dirZ, oz = originShift;
@@ -404,6 +409,7 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
                 t.retryK1 = static_cast<float>(1.0 - 0.5 * (1.0 / lo + 1.0 / hi));
                 t.retryRho0 = static_cast<float>(a / lo);
                 t.retrySpread = static_cast<float>(0.5 * (1.0 / lo - 1.0 / hi));
+                t.retryMaxD = static_cast<float>(0.99 * dirZ * std::sqrt(R * R - a * a) / a);
             }
         }
     }
@@ -423,7 +429,8 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
                 const float theta = std::atan2(o0y, o0x), sn = std::sin(theta), cs = std::cos(theta);
                 const float ccx = translation * (cs - sn) - o0x * t.retryK1, ccy = translation * (sn + cs) - o0y * t.retryK1;
                 const float reach = (t.retryRho0 + dist * t.retrySpread + std::fabs(maxScale) * 1.4158f) * 1.01f + 1.0e-4f;
-                if (ccx * ccx + ccy * ccy > reach * reach) ++hits;
+                const float dxyMax = std::fabs(maxScale) * 1.4158f + std::fabs(translation) * 1.4158f + dist;
+                if (ccx * ccx + ccy * ccy > reach * reach && dxyMax <= t.retryMaxD) ++hits;
             }
         static const double minShare = [] { const char *e = std::getenv("ZOIC_RETRY_DEAD_MIN_SHARE"); return e ? std::atof(e) : 0.02; }();
         if (hits < minShare * grid * grid) t.retryOn = 0;

@@ -79,6 +79,9 @@ struct KolbTable {
     float retryK1;        // centre of that region = o.xy * retryK1
     float retryRho0;      // its radius = retryRho0 + |o.xy| * retrySpread
     float retrySpread;
+    float retryMaxD;      // the bounds above hold for hits on the VERTEX-side cap of the rear sphere; the root the reference takes
+                          // (zoic.cpp:986: ONE signed root, t < 0 never rejected) can only land on the opposite |xy| <= a cap
+                          // when |d.xy| / dirZ > sqrt(R^2 - a^2) / a: rays with |d.xy| above retryMaxD are never classified
     Surface surf[kMaxSurfaces];
     FastSurface fsurf[kMaxSurfaces];
     float lutMaxScale[kLutEntries];  // boundingBox2d::getMaxScale per LUT entry (zoic.cpp:503-517)
