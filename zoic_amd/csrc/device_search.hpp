@@ -75,12 +75,15 @@ __device__ __forceinline__ int cell_resolve(const uint4 rec, float u, bool inRan
     return static_cast<int>((ge0 & !ge1) ? (pair >> 16) : (pair & 0xffffu));   // k = 1 -> high half of .z
 }
 
-// Lens sample through the cell records: `ldsRowCells` = the workgroup's LDS copy of BokehTables::rowCells.
-// Identical indices to bokeh_sample / std::upper_bound (zoic.cpp:420-485).
-template <bool EXACT_DIVIDE>
-__device__ __forceinline__ V2 bokeh_sample_cells(const BokehTables &B, const float *ldsRowCells, int x, int y, float uRow, float uCol)
+// Lens sample through the cell records, in two halves so that a kernel can request the column record of a sample one pass
+// before it needs it (kolb_pool_body.hpp): bokeh_cells_issue resolves the row from the workgroup's LDS copy of
+// BokehTables::rowCells and issues the ONE dependent global load (the column cell record of that row); bokeh_cells_finish
+// turns the record into the lens point.  Identical indices to bokeh_sample / std::upper_bound (zoic.cpp:420-485).
+struct CellProbe { uint4 rec; int row; uint32_t cellIndex; };
+
+__device__ __forceinline__ CellProbe bokeh_cells_issue(const BokehTables &B, const float *ldsRowCells, int y, float uRow, float uCol)
 {
-    bool inR, inC, excR, excC;
+    bool inR, inC, excR;
     const int gr = cell_of(uRow, B.rowCellCount, inR);
     const int gc = cell_of(uCol, B.colCellCount, inC);
     int row = cell_resolve(reinterpret_cast<const uint4 *>(ldsRowCells)[gr], uRow, inR, excR);
@@ -93,11 +96,23 @@ __device__ __forceinline__ V2 bokeh_sample_cells(const BokehTables &B, const flo
             row = B.rowIndices[r];
         }
     }
-    const uint32_t cellIndex = static_cast<uint32_t>(row) * static_cast<uint32_t>(B.colCellCount) + static_cast<uint32_t>(gc);
-    int col = cell_resolve(reinterpret_cast<const uint4 *>(B.colCells)[cellIndex], uCol, inC, excC);
+    CellProbe p;
+    p.row = row;
+    p.cellIndex = static_cast<uint32_t>(row) * static_cast<uint32_t>(B.colCellCount) + static_cast<uint32_t>(gc);
+    p.rec = reinterpret_cast<const uint4 *>(B.colCells)[p.cellIndex];
+    return p;
+}
+
+template <bool EXACT_DIVIDE>
+__device__ __forceinline__ V2 bokeh_cells_finish(const BokehTables &B, int x, int y, float uCol, const CellProbe &p)
+{
+    const bool inC = (uCol >= 0.0f) & (uCol < 1.0f);
+    bool excC;
+    const int row = p.row;
+    int col = cell_resolve(p.rec, uCol, inC, excC);
     if (__ballot(excC) != 0ull) {
         if (excC) {
-            const uint32_t bnd = B.colBounds[cellIndex];
+            const uint32_t bnd = B.colBounds[p.cellIndex];
             const int lo = inC ? static_cast<int>(bnd & 0xffffu) : 0, hi = inC ? static_cast<int>(bnd >> 16) : x;
             const int start = row * x;
             int c = lo + upper_bound_idx(B.cdfColumn + start + lo, hi - lo, uCol);
@@ -112,6 +127,12 @@ __device__ __forceinline__ V2 bokeh_sample_cells(const BokehTables &B, const flo
     else  // fast mode: wave-uniform reciprocals (exact when x, y are powers of two)
         return V2{flippedRow * (2.0f * __builtin_amdgcn_rcpf(static_cast<float>(x))),
                   flippedColumn * (2.0f * __builtin_amdgcn_rcpf(static_cast<float>(y)))};
+}
+
+template <bool EXACT_DIVIDE>
+__device__ __forceinline__ V2 bokeh_sample_cells(const BokehTables &B, const float *ldsRowCells, int x, int y, float uRow, float uCol)
+{
+    return bokeh_cells_finish<EXACT_DIVIDE>(B, x, y, uCol, bokeh_cells_issue(B, ldsRowCells, y, uRow, uCol));
 }
 
 }  // namespace zoic

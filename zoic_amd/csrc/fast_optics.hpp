@@ -63,10 +63,10 @@ __device__ __forceinline__ float atan2_f32(float y, float x)
 }
 
 // The per-surface constants are wave-uniform kernel arguments: read through a pointer in the CONSTANT address space they
-// stay s_loads (SGPR operands).  The persistent pass loop re-derives this pointer every pass behind an empty asm
-// (launder_table): otherwise LLVM hoists all NS x 10 loads out of the pass loop as loop invariants, runs out of SGPRs and
-// spills them to VGPR lanes -- every constant then costs a v_readlane per use (measured: 568 v_readlane + VGPR scratch
-// spills in the decision-safe kernel, -25 % throughput) instead of a scalar-cache hit.
+// stay s_loads (SGPR operands).  The pass loop re-derives this pointer every pass behind an empty asm (launder_table):
+// otherwise LLVM hoists all NS x 10 loads out of the pass loop as loop invariants, runs out of SGPRs and spills them to
+// VGPR lanes -- every constant then costs a v_readlane per use (measured: 568 v_readlane + VGPR scratch spills in the
+// decision-safe kernel, -25 % throughput) instead of a scalar-cache hit.
 #ifndef ZOIC_GUARD_PIN
 #define ZOIC_GUARD_PIN 1
 #endif
@@ -89,15 +89,12 @@ __device__ __forceinline__ FastSurface load_surface(FastSurfaceTable t, int i)
 {
     if constexpr (PIN) asm volatile("" : "+s"(t));   // the loads of interface i are issued here, not hoisted to the top of the pass
     FastSurface S;
-    S.center = t[i].center; S.radius2 = t[i].radius2; S.sign = t[i].sign; S.housing2 = t[i].housing2; S.invRadius = t[i].invRadius;
-    S.eta = t[i].eta; S.etaInvAbsR = t[i].etaInvAbsR; S.e2InvR2 = t[i].e2InvR2; S.oneMinusEta2 = t[i].oneMinusEta2;
-    S.bandHousing = t[i].bandHousing; S.pad0 = S.pad1 = 0.0f;
+    S.center = t[i].center; S.radius2 = t[i].radius2; S.sign = t[i].sign; S.housing2 = t[i].housing2;
+    S.eta = t[i].eta; S.qOffset = t[i].qOffset; S.krScale = t[i].krScale;
+    S.housingLo = t[i].housingLo; S.housingHi = t[i].housingHi;
+    S.pad0 = S.pad1 = S.pad2 = 0.0f;
     return S;
 }
-
-// Decision-safe mode: only ill-conditioned interfaces carry a guard band (bandHousing > 0, set by the host: in practice the
-// stop, see lens_system.cpp fill_surfaces); the test is a wave-uniform scalar branch, so well-conditioned interfaces pay nothing.
-__device__ __forceinline__ bool surface_is_guarded(const FastSurface &S) { return __builtin_bit_cast(int, S.bandHousing) > 0; }
 
 __device__ __forceinline__ float uniform_f32(float v)
 {
@@ -108,9 +105,9 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
 {
     FastSurface r;
     r.center = uniform_f32(s.center); r.radius2 = uniform_f32(s.radius2); r.sign = uniform_f32(s.sign);
-    r.housing2 = uniform_f32(s.housing2); r.invRadius = uniform_f32(s.invRadius); r.eta = uniform_f32(s.eta);
-    r.etaInvAbsR = uniform_f32(s.etaInvAbsR); r.e2InvR2 = uniform_f32(s.e2InvR2); r.oneMinusEta2 = uniform_f32(s.oneMinusEta2);
-    r.bandHousing = uniform_f32(s.bandHousing); r.pad0 = r.pad1 = 0.0f;
+    r.housing2 = uniform_f32(s.housing2); r.eta = uniform_f32(s.eta); r.qOffset = uniform_f32(s.qOffset);
+    r.krScale = uniform_f32(s.krScale); r.housingLo = uniform_f32(s.housingLo); r.housingHi = uniform_f32(s.housingHi);
+    r.pad0 = r.pad1 = r.pad2 = 0.0f;
     return r;
 }
 
@@ -119,65 +116,75 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
 //   d : raw direction on entry; the refracted unit direction on exit.  If the ray dies before its first refraction d is
 //       left untouched -- the partial state the reference hands out for rays that run out of tries (zoic.cpp:1951-1961).
 // With |u| = 1 and the hit on the sphere:  N = (c - hit)/R,  cos(i) = -(u.N) = thc/|R|  (no dot product),
-//   1 - cs2 = (1 - eta^2) + (eta/R)^2 thc^2,   TIR <=> 1 - cs2 < 0,
-//   u' = eta u + (eta cos(i) - sqrt(1 - cs2)) N      (|u'| = 1 again).
-// ~28 VALU + 2 v_sqrt_f32 per interface instead of ~52.
+//   1 - cs2 = (1 - eta^2) + (eta/R)^2 thc^2 = (eta/R)^2 q,   q = thc^2 + (1 - eta^2) R^2 / eta^2,   TIR <=> q < 0,
+//   u' = eta u + kr (c - hit),   kr = (eta cos(i) - sqrt(1 - cs2)) / R = eta/(|R| R) (thc - sqrt(q))      (|u'| = 1 again).
+// The squared distance of the origin from the axis is carried from interface to interface (it is the h^2 of the previous
+// hit): |L|^2 = h^2 + Lz^2.  Per interface: 27 VALU + 2 v_sqrt_f32 + 3 compares (4 with a guard band).
 //
-// One interface of the fast trace.  Returns 0 = passed, 1 = clipped (o, u untouched), 2 = total internal reflection
-// (o advanced, u untouched) -- the two partial states the reference can leave.
-__device__ __forceinline__ int fast_interface(const FastSurface &S, bool isStop, float userAperture2, V3 &o, V3 &u, bool *near = nullptr)
+// FastHit: the arithmetic of ONE interface, shared by the predicated trace, the branchy trace and the interface-0 test, so that
+// the three agree bit for bit on every decision.
+struct FastHit { float w, thc, h2; V3 hit; bool miss; };
+__device__ __forceinline__ FastHit fast_hit(const FastSurface &S, const V3 &o, float oAxis2, const V3 &u)
 {
+    FastHit r;
     const float Lz = S.center - o.z;
     const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
-    const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
-    const float w = fabsf(S.radius2 - d2);                 // thc^2
-    const float thc = fsqrt_fast(w);
-    const float t = tca + thc * S.sign;
-    const V3 hit{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
-    const float h2 = hit.x * hit.x + hit.y * hit.y;
-    const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
-    const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
-    if (near) *near = surface_is_guarded(S) && fabsf(h2 - S.housing2) < S.bandHousing;
-    if (clipped) return 1;
-    o = hit;
-    if (oneMinusCs2 < 0.0f) return 2;                       // cs2 > 1 (only reachable when eta > 1)
-    const float k = thc * S.etaInvAbsR - fsqrt_fast(oneMinusCs2);
-    const float kr = k * S.invRadius;                       // k * N = kr * (c - hit)
-    u = V3{u.x * S.eta - hit.x * kr, u.y * S.eta - hit.y * kr, u.z * S.eta + (S.center - hit.z) * kr};
+    const float d2 = (oAxis2 + Lz * Lz) - tca * tca;
+    const float rd = S.radius2 - d2;
+    r.miss = rd < 0.0f;                                     // d2 > radius2 (zoic.cpp:981)
+    r.w = fabsf(rd);                                        // thc^2
+    r.thc = fsqrt_fast(r.w);
+    const float t = tca + r.thc * S.sign;
+    r.hit = V3{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
+    r.h2 = r.hit.x * r.hit.x + r.hit.y * r.hit.y;
+    return r;
+}
+// Snell at the hit point: returns q (TIR <=> q < 0) and writes the refracted unit direction
+__device__ __forceinline__ float fast_refract(const FastSurface &S, const FastHit &h, V3 &u)
+{
+    const float q = h.w + S.qOffset;
+    const float kr = (h.thc - fsqrt_fast(fabsf(q))) * S.krScale;
+    u = V3{u.x * S.eta - h.hit.x * kr, u.y * S.eta - h.hit.y * kr, u.z * S.eta + (S.center - h.hit.z) * kr};
+    return q;
+}
+
+// Decision-safe mode: only ill-conditioned interfaces carry a guard band (housingLo < housingHi, set by the host: in practice
+// the stop, lens_system.cpp fill_surfaces).  h^2 in (housingLo, housingHi] is too close to call; on unguarded interfaces both
+// edges equal housing2 and the interval is empty.
+__device__ __forceinline__ bool surface_is_guarded(const FastSurface &S) { return S.housingLo < S.housingHi; }
+
+// One interface of the branchy trace.  Returns 0 = passed, 1 = clipped (o, u untouched), 2 = total internal reflection
+// (o advanced, u untouched) -- the two partial states the reference can leave.
+__device__ __forceinline__ int fast_interface(const FastSurface &S, V3 &o, float &oAxis2, V3 &u, bool *near = nullptr)
+{
+    const FastHit h = fast_hit(S, o, oAxis2, u);
+    if (near) *near = (h.h2 > S.housingLo) & !(h.h2 > S.housingHi);
+    if (h.miss | (h.h2 > S.housing2)) return 1;              // the stop's housing2 includes the user aperture
+    o = h.hit;
+    oAxis2 = h.h2;
+    V3 un = u;
+    if (fast_refract(S, h, un) < 0.0f) return 2;             // cs2 > 1 (only reachable when eta > 1)
+    u = un;
     return 0;
 }
 
-// Does a ray clear interface 0 (first sphere hit + rear-element housing)?  Same arithmetic as the first half of
-// fast_interface; used by the kernel's candidate search so that tries dying at the rear element never pay for a trace.
-__device__ __forceinline__ bool interface0_clear_fast(const FastSurface &S, V3 o, V3 d)
+// Does a ray clear interface 0 (first sphere hit + rear-element housing)?  The first half of an interface; used by the
+// kernel's candidate search so that tries dying at the rear element never pay for a trace.  GUARD: `near` is set when the
+// housing decision lies inside its guard band (the answer is then not used: the ray goes to STRICT).
+template <bool GUARD>
+__device__ __forceinline__ bool interface0_clear_fast(const FastSurface &S, V3 o, V3 d, bool &near)
 {
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
     const V3 u{d.x * inv, d.y * inv, d.z * inv};
-    const float Lz = S.center - o.z;
-    const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
-    const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
-    const float thc = fsqrt_fast(fabsf(S.radius2 - d2));
-    const float t = tca + thc * S.sign;
-    const float hx = o.x + u.x * t, hy = o.y + u.y * t;
-    const float h2 = hx * hx + hy * hy;
-    return !((d2 > S.radius2) | (h2 > S.housing2));
-}
-
-// The same test for the decision-safe mode: `near` is set when the housing decision lies inside its guard band (tables.hpp).
-__device__ __forceinline__ bool interface0_clear_fast_guard(const FastSurface &S, V3 o, V3 d, bool &near)
-{
-    const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
-    const V3 u{d.x * inv, d.y * inv, d.z * inv};
-    const float Lz = S.center - o.z;
-    const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
-    const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
-    const float w = fabsf(S.radius2 - d2);
-    const float thc = fsqrt_fast(w);
-    const float t = tca + thc * S.sign;
-    const float hx = o.x + u.x * t, hy = o.y + u.y * t;
-    const float h2 = hx * hx + hy * hy;
-    near = fabsf(h2 - S.housing2) < S.bandHousing;
-    return !((d2 > S.radius2) | (h2 > S.housing2));
+    const FastHit h = fast_hit(S, o, o.x * o.x + o.y * o.y, u);
+    if constexpr (GUARD) {
+        const bool aboveLo = h.h2 > S.housingLo;
+        near = aboveLo & !(h.h2 > S.housingHi);
+        return !(h.miss | aboveLo);
+    } else {
+        near = false;
+        return !(h.miss | (h.h2 > S.housing2));
+    }
 }
 
 // Rolled, branchy trace for any interface count.  It leaves exactly the partial state of the reference on every exit
@@ -186,6 +193,7 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
 {
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
     V3 u{d.x * inv, d.y * inv, d.z * inv};
+    float oAxis2 = o.x * o.x + o.y * o.y;
     bool ok = true, refracted = false;
     const int n = T.lensCount;
     // Every lane still in the loop is at the same surface, but the divergent exits hide that from the compiler;
@@ -196,7 +204,7 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
         const FastSurface S = uniform_surface(Snext);
         Snext = T.fsurf[(iu + 1 < n) ? iu + 1 : iu];
         bool near = false;
-        const int r = fast_interface(S, iu == T.apertureElement, T.userAperture2, o, u, unsure ? &near : nullptr);
+        const int r = fast_interface(S, o, oAxis2, u, unsure ? &near : nullptr);
         if (unsure) *unsure |= near;
         if (r != 0) { if (r == 2) ++tirCount; ok = false; break; }
         refracted = true;
@@ -207,55 +215,48 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
 }
 
 // Predicated, fully unrolled trace for a lens with exactly NS interfaces: NO divergent control flow.  Every lane
-// evaluates every interface; a lane that is clipped or totally reflected only clears its bit in the `alive` mask
-// (v_cmp -> SGPR pair, s_andn2).  Dead lanes keep computing on garbage, which costs nothing: a wave issues each VALU
-// instruction once whatever its exec mask.  The rolled loop above spends ~33 scalar instructions per interface on
-// exec-mask bookkeeping and loop control next to 37 VALU, and the scalar unit became the limiter; here an interface
-// is ~31 VALU + ~6 SALU, and its table words are s_loads at fixed kernel-argument offsets (SGPR operands: staging
-// the table in LDS instead was measured 36 % slower on C4 -- VGPR copies, no scalar operands).  A wave-uniform test
-// every second interface leaves the trace as soon as no lane is alive (heavily vignetted passes).
-// Returns alive; o/u are the exit point and unit direction for alive lanes (unspecified for dead ones -- rays that
-// finish dead get their reference partial state from trace_lens_fast_rolled).
-// GUARD (decision-safe mode): `unsure` collects, for lanes still alive at a guarded interface, whether its clip decision
-// lies inside the guard band.
+// evaluates every interface; a lane that is clipped or totally reflected only clears its bit in the `alive` mask.  The
+// masks are plain 64-bit scalars (one v_cmp into an SGPR pair per decision, s_and / s_andn2 / s_or to combine them): no
+// v_cndmask, no exec-mask bookkeeping.  Dead lanes keep computing on garbage, which costs nothing: a wave issues each VALU
+// instruction once whatever its exec mask.  The table words are s_loads at fixed kernel-argument offsets (SGPR operands:
+// staging the table in LDS instead was measured 36 % slower on C4 -- VGPR copies, no scalar operands).  A wave-uniform
+// test every second interface leaves the trace as soon as no lane is alive (heavily vignetted passes).
+// Returns the alive mask; o/d are the exit point and unit direction for alive lanes (unspecified for dead ones -- rays that
+// finish dead get their reference partial state from trace_lens_fast_rolled).  tirMask: lanes that were totally reflected.
+// GUARD (decision-safe mode): unsureMask collects the lanes still alive at a guarded interface whose clip decision lies inside
+// the guard band.
 template <int NS, bool GUARD = false>
-__device__ __forceinline__ bool trace_lens_fast_pred(FastSurfaceTable surf, V3 &o, V3 &d, uint32_t &tirCount, bool alive0,
-                                                     bool *unsureOut = nullptr)
+__device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTable surf, V3 &o, V3 &d, unsigned long long alive0,
+                                                                   unsigned long long &tirMask, unsigned long long &unsureMask)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
     const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
     V3 u{d.x * inv, d.y * inv, d.z * inv};
-    bool alive = alive0, tirSeen = false;   // alive0: lanes without a candidate ride along dead
-    bool unsure = false;
-    bool anyAlive = true;  // wave-uniform
+    float oAxis2 = o.x * o.x + o.y * o.y;
+    unsigned long long alive = alive0, tirSeen = 0ull, unsure = 0ull;   // alive0: lanes without a candidate ride along dead
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;   // wave-uniform early out, every 2nd interface
-        if (!anyAlive) continue;
+        if (i >= 2 && (i & 1) == 0 && alive == 0ull) break;   // wave-uniform early out, every 2nd interface
         const FastSurface S = load_surface<GUARD && (ZOIC_GUARD_PIN != 0)>(surf, i);
-        const float Lz = S.center - o.z;
-        const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
-        const float d2 = (o.x * o.x + o.y * o.y + Lz * Lz) - tca * tca;
-        const float w = fabsf(S.radius2 - d2);                 // thc^2
-        const float thc = fsqrt_fast(w);
-        const float t = tca + thc * S.sign;
-        o = V3{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};    // hit point
-        const float h2 = o.x * o.x + o.y * o.y;
-        const bool clipped = (d2 > S.radius2) | (h2 > S.housing2);   // the stop's housing2 includes the user aperture
-        const float oneMinusCs2 = S.oneMinusEta2 + S.e2InvR2 * w;
-        const bool tirHere = oneMinusCs2 < 0.0f;
+        const FastHit h = fast_hit(S, o, oAxis2, u);
+        unsigned long long clipped = __ballot(h.miss);
         if constexpr (GUARD) {
-            unsure |= alive & (fabsf(h2 - S.housing2) < S.bandHousing);   // never true on unguarded interfaces (band 0): no branch
-        }
-        tirSeen |= alive & !clipped & tirHere;                  // counted only by rays that reached the refraction
-        alive &= !clipped & !tirHere;
-        const float k = thc * S.etaInvAbsR - fsqrt_fast(fabsf(oneMinusCs2));
-        const float kr = k * S.invRadius;
-        u = V3{u.x * S.eta - o.x * kr, u.y * S.eta - o.y * kr, u.z * S.eta + (S.center - o.z) * kr};
+            // two compares: above the band's lower edge = clipped or too close to call; not above its upper edge as well =
+            // too close to call (then the ray goes to STRICT and `clipped` is never used).  Unguarded: both edges = housing2.
+            const unsigned long long aboveLo = __ballot(h.h2 > S.housingLo);
+            unsure |= alive & aboveLo & ~__ballot(h.h2 > S.housingHi);
+            clipped |= aboveLo;
+        } else clipped |= __ballot(h.h2 > S.housing2);   // the stop's housing2 includes the user aperture
+        o = h.hit;
+        oAxis2 = h.h2;
+        const unsigned long long tirHere = __ballot(fast_refract(S, h, u) < 0.0f);
+        alive &= ~clipped;
+        tirSeen |= alive & tirHere;                      // counted only by rays that reached the refraction
+        alive &= ~tirHere;
     }
-    tirCount += tirSeen ? 1u : 0u;
+    tirMask = tirSeen;
+    unsureMask = unsure;
     d = u;
-    if constexpr (GUARD) *unsureOut = unsure;
     return alive;
 }
 

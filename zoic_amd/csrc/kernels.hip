@@ -1,15 +1,12 @@
-// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for zoic's per-sample lens hot path, STRICT mode,
-// plus the small service kernels (sample synthesis, exit-pupil LUT probes, Arnold AoS packing).
+// kernels.hip -- the small hand-written gfx950 (CDNA4, wave64) kernels of zoic's per-sample lens hot path: the streaming
+// thin-lens kernel, sample synthesis, the exit-pupil LUT probes and the Arnold AoS packing.  (The Kolb kernels:
+// kolb_pool_body.hpp; the thin-lens kernel with optical vignetting: thin_refill.hip.)
 //
-// Mapping (DESIGN.md "kernels"): one camera sample per lane, 256-lane workgroups (4 waves = one per SIMD),
-// a grid capped at 8 workgroups per CU that strides over the sample buffer.  The lens prescription and the
-// exit-pupil LUT arrive as a by-value kernel argument: wave-uniform, fetched by s_load through the scalar
-// cache, indexed by the (uniform) surface counter -- no LDS and no VGPRs spent on tables.  Sample loads are
-// one 16-byte global_load_dwordx4 per lane (1 KiB per wave instruction); results leave as one 32-byte record
-// per ray (two 16-byte stores per lane).  The path is scalar FP32 per ray: no contraction to feed MFMA.
-//
-// STRICT = the reference's operation order and f64 intermediates, no FMA contraction (see optics.hpp): bit-exact
-// against the CPU oracle.  The FAST variant lives in kolb_fast.hip.
+// Mapping: one camera sample per lane, 256-lane workgroups (4 waves = one per SIMD), a grid capped at 8 workgroups per
+// CU that strides over the sample buffer.  Tables arrive as by-value kernel arguments: wave-uniform, fetched by s_load
+// through the scalar cache -- no LDS and no VGPRs spent on them.  Sample loads are one 16-byte global_load_dwordx4 per lane
+// (1 KiB per wave instruction); results leave as one 32-byte record per ray.  The path is scalar FP32 per ray: no
+// contraction to feed MFMA.  STRICT arithmetic (optics.hpp): bit-exact against the CPU oracle.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -22,10 +19,6 @@
 #include "optics.hpp"
 
 #pragma STDC FP_CONTRACT OFF
-
-#ifndef ZOIC_DEFAULT_KOLB_VARIANT
-#define ZOIC_DEFAULT_KOLB_VARIANT "refill"
-#endif
 
 namespace zoic {
 
@@ -64,66 +57,6 @@ __device__ __forceinline__ V2 sample_lens(bool useImage, const BokehTables &B, c
 }
 
 extern __shared__ __align__(16) float thinDynLds[];   // bokeh row cell records (thin-lens kernel), after the static LDS
-
-// ------------------------------------------------------------------------------------- RAYTRACED, strict
-__global__ __launch_bounds__(kBlock) void kolb_rays_strict_kernel(const KolbTable T, const BokehTables B,
-                                                                  const float4 *__restrict__ samples,
-                                                                  const uint4 *__restrict__ rngStates, uint64_t rayBase,
-                                                                  uint64_t n, RayRecord *__restrict__ out, DeviceCounters *counters)
-{
-    uint32_t succ = 0, vign = 0, tir = 0;
-    const bool useImage = T.useImage != 0;
-    const float *rowCells = nullptr;   // the A/B baseline kernel keeps the pyramid search
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-        const float4 s = samples[i];  // (sx, sy, lensx, lensy)
-        Rng rng;
-        if (rngStates) { const uint4 r = rngStates[i]; rng = Rng{r.x, r.y, r.z, r.w}; }
-        else rng = rng_for_ray(T.seed, rayBase + i);
-
-        // sensor point, zoic.cpp:1853-1855
-        const V3 o0{s.x * T.halfSensor, s.y * T.halfSensor, T.originShift};
-        V2 lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, s.z, s.w);  // zoic.cpp:1870
-        float maxScale = 0.0f, translation = 0.0f, sn = 0.0f, cs = 1.0f;
-        uint32_t lutMiss = 0;
-        V3 o = o0, d;
-        if (!T.useLUT) {  // zoic.cpp:1873-1877
-            d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
-        } else {          // zoic.cpp:1889-1925
-            const float dist = fabsf(sqrtf(o.x * o.x + o.y * o.y));
-            const float theta = static_cast<float>(atan2(static_cast<double>(o.y), static_cast<double>(o.x)));
-            sn = fast_sin(theta);
-            cs = fast_cos(theta);
-            lutMiss = lut_lookup(T, dist, maxScale, translation) ? 0u : 1u;
-            lens.x *= maxScale; lens.y *= maxScale;
-            lens.x += translation;
-            const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
-            d = V3{rx - o.x, ry - o.y, T.dirZ};
-        }
-        int tries = 0;
-        while (!trace_lens_strict(T, o, d, tir) && tries <= kMaxTries) {  // zoic.cpp:1879 / 1927
-            o = o0;
-            const float u = rng_unit(xor128(rng));
-            const float v = rng_unit(xor128(rng));
-            lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, u, v);
-            if (!T.useLUT) {
-                d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
-            } else {
-                lens.x *= maxScale; lens.y *= maxScale;
-                lens.x += translation; lens.y += translation;  // both components on retries, zoic.cpp:1933
-                const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
-                d = V3{rx - o.x, ry - o.y, T.dirZ};
-            }
-            ++tries;
-        }
-        float w = 1.0f;
-        if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ;  // zoic.cpp:1951-1957
-        if (T.exposureOn) w *= T.exposureMul;                      // zoic.cpp:1981-1987
-        store_ray_record(out, i, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,  // zoic.cpp:1960-1961
-                         (tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1) | (lutMiss << 6));
-    }
-    flush_counters(counters, succ, vign, tir);
-}
 
 // ------------------------------------------------------------------------------------- THINLENS
 // zoic.cpp:1771-1846 + empericalOpticalVignetting zoic.cpp:1297-1305.  All f32; ~60 flop / 44 B: HBM-bound.
@@ -265,39 +198,6 @@ static inline unsigned grid_for(uint64_t n)
     return static_cast<unsigned>(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
 }
 
-int launch_kolb_fast(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, void *stream);
-int launch_kolb_refill(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                       uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                       int mode, uint32_t *d_scratch, void *stream);
-int launch_kolb_pool(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                     int mode, uint32_t *d_scratch, void *stream);
-
-// ZOIC_KOLB_VARIANT = refill (persistent lane refill, default) | simple (one sample per lane, retry loop in the lane:
-// the A/B baseline of DESIGN.md's ladder).
-static const char *kolb_variant()
-{
-    const char *e = std::getenv("ZOIC_KOLB_VARIANT");
-    return e ? e : ZOIC_DEFAULT_KOLB_VARIANT;
-}
-static bool use_simple_variant() { return std::strcmp(kolb_variant(), "simple") == 0; }
-
-int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
-                     int mode, uint32_t *d_scratch, void *stream)
-{
-    if (n == 0) return 0;
-    static const bool pool = std::strcmp(kolb_variant(), "pool") == 0;
-    if (pool) return launch_kolb_pool(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
-    if (!use_simple_variant()) return launch_kolb_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
-    if (mode != 0) return launch_kolb_fast(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, stream);
-    hipLaunchKernelGGL(kolb_rays_strict_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), table, bokeh,
-                       reinterpret_cast<const float4 *>(d_samples), reinterpret_cast<const uint4 *>(d_rng), rayBase, n, out,
-                       d_counters);
-    return static_cast<int>(hipGetLastError());
-}
-
 int launch_thin_refill(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng, uint64_t rayBase,
                        uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, bool fast, void *stream);
 
@@ -306,8 +206,7 @@ int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const flo
                      void *stream)
 {
     if (n == 0) return 0;
-    static const bool simpleThin = [] { const char *e = std::getenv("ZOIC_THIN_VARIANT"); return e && std::string(e) == "simple"; }();
-    if (table.useDof && table.ovDistance > 0.0f && !simpleThin)   // the retry loop of zoic.cpp:1804-1819 can run
+    if (table.useDof && table.ovDistance > 0.0f)   // the retry loop of zoic.cpp:1804-1819 can run
         return launch_thin_refill(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, fast, stream);
     const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
     hipLaunchKernelGGL(thin_rays_kernel, dim3(grid_for(n)), dim3(kBlock), ldsWords * sizeof(float), static_cast<hipStream_t>(stream),

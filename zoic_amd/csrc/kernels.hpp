@@ -54,20 +54,17 @@ constexpr unsigned kRedoCountOffset = 32;     // length of the STRICT kernel's w
 constexpr unsigned kRedoCursorOffset = 16;    // partition p's cursor of that kernel: block[16 + p * kCursorPartStride]
 // precision modes of the Kolb launch (zoic_precision): 0 strict, 1 fast decision-safe, 2 fast unchecked.
 // d_scratch: kolb_scratch_dwords() dwords -- the work list of mode 1 (one dword per sample of a launch, launches cover up to
-// 2^31 samples), then, for cameras with retry-dead rays (KolbTable::retryOn), the finish kernel's byte map (one byte per
-// sample, padded to 1024); may be null when that is 0
-inline size_t kolb_scratch_dwords(const KolbTable &table, uint64_t n, int mode)
+// 2^31 samples); may be null when that is 0
+inline size_t kolb_scratch_dwords(const KolbTable &, uint64_t n, int mode)
 {
-    const size_t per = static_cast<size_t>(n < (1ull << 31) ? n : (1ull << 31));
-    return (mode == 1 ? per : 0) + (table.retryOn ? (per + 1023) / 1024 * 256 : 0);
+    return mode == 1 ? static_cast<size_t>(n < (1ull << 31) ? n : (1ull << 31)) : 0;
 }
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                      int mode, uint32_t *d_scratch, void *stream);
 
 // camera_create_ray, THINLENS branch (zoic.cpp:1771-1846).  With optical vignetting on (retries possible) the
-// persistent-wave refill kernel of thin_refill.hip runs, otherwise the streaming kernel; ZOIC_THIN_VARIANT=simple
-// forces the streaming kernel (A/B).
+// persistent-wave refill kernel of thin_refill.hip runs, otherwise the streaming kernel.
 int launch_thin_rays(const ThinTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                      uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor, bool fast,
                      void *stream);   // fast: only the refill kernel has a fast arithmetic variant (the streaming kernel is HBM-bound)

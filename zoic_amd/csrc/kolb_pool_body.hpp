@@ -2,7 +2,7 @@
 // (compiled twice: kolb_pool.hip for cameras without retry-dead rays, kolb_pool_dead.hip for those with)
 //
 // Why.  camera_create_ray retries a rejected sample up to 26 more times (zoic.cpp:1927-1947).  Round 2's kernel
-// (kolb_refill_body.hpp) kept a ray in its lane until it was finished and refilled the free lanes of every pass from a
+// (git history: kolb_refill_body.hpp) kept a ray in its lane until it was finished and refilled the free lanes of every pass from a
 // sample window: ballot + prefix sum + four ds_bpermute + the per-ray set-up (atan2, parabola sin/cos, LUT lerp) executed
 // for the handful of lanes that happened to be free, finished records parked in LDS, ~60 scalars and ~20 per-lane values
 // alive across the pass loop (48 SGPR spills in the headline instantiation).  59 % of the instructions of the headline
@@ -23,15 +23,156 @@
 // (tables.hpp KolbTable::retry*) in a second LDS list and complete them 64 at a time INSIDE this kernel (finish_dead_ray
 // at full lane width) -- the byte map, its memset and the separate finish kernel of round 2 are gone.
 //
-// Order of memory operations in a pass (vmcnt is ONE in-order counter): pool pop (LDS) -> candidate search (the bokeh
-// sampler's dependent global load) -> request the next fresh batch -> trace -> record stores -> pool push (LDS).  The next
-// pass waits for its batch with vmcnt(2): the two record stores issued after the request are never waited for.
+// Order of memory operations in a pass (vmcnt is ONE in-order counter): pool pop (LDS) -> candidate search (retries: the
+// bokeh sampler's dependent global load) -> the fresh batches move up (IMAGE: the column cell record of the next batch's
+// first lens sample is requested -- its LDS -> global chain flies under this pass's trace -- then the batch after it) ->
+// trace -> record stores -> pool push (LDS).  The next pass waits for its probe and its samples with vmcnt(2+): the two
+// record stores issued after them are never waited for.
 #pragma once
-#include "kolb_refill_body.hpp"   // RefillArgs / ZOIC_KARG, setup_ray, retry_direction, finish_dead_ray
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "kolb_device.hpp"
+#include "work_cursor.hpp"
 
 #pragma STDC FP_CONTRACT OFF
 
 namespace zoic {
+
+// Kernel arguments that only rare paths read (chunk claim, first retry, work-list flush, exit) are fetched from the kernarg
+// segment where they are used instead of living in SGPRs for the whole kernel: the pass loop carries ~60 scalars, the
+// budget is 94, and what does not fit is spilled to VGPR lanes and paid for with a v_readlane per use inside the trace.
+// KolbKernelArgs mirrors the kernels' parameter list (HIP lays kernel arguments out like a C struct; offsets checked against the
+// code object's metadata, tools/isa_mix.py).
+struct KolbKernelArgs {
+    KolbTable T; BokehTables B; const float4 *samples; const uint4 *rngStates; uint64_t rayBase; uint32_t n; RayRecord *out;
+    DeviceCounters *counters; unsigned int *workCursor; uint32_t ldsWords, chunkRays, chunksPerPart, minSearching;
+    uint32_t *redoList; unsigned int *redoCount;             // GUARD kernel: appends the rays it cannot decide; LISTED kernel: reads them
+};
+template <class V, size_t OFFSET>
+__device__ __forceinline__ V kernarg_field()
+{
+    typedef const char __attribute__((address_space(4))) *KernargBytes;
+    KernargBytes base = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));   // loaded here, every time: not hoisted into a long-lived SGPR
+    return *(const V __attribute__((address_space(4))) *)(base + OFFSET);
+}
+#define ZOIC_KARG(field) kernarg_field<decltype(KolbKernelArgs::field), offsetof(KolbKernelArgs, field)>()
+
+// One body, four kernel families.  A decision-safe FAST launch is a pipeline of two kernels on the caller's stream:
+//   GUARD (FAST only): every accept/reject decision of a try at a guarded interface (tables.hpp FastSurface::housingLo/Hi: in
+//       practice the stop) is checked against its guard band; a ray with a decision too close to call is dropped where it
+//       stands -- no record, no counter -- and its index goes to the work list `redoList`;
+//   LISTED (STRICT only) = the kernel that runs next on the stream and evaluates exactly the listed rays from scratch in
+//       the reference's arithmetic (per-ray retry streams make that the same ray).
+// Together: every ray's try count, weight and flags are those of a STRICT evaluation unless FAST and STRICT disagree on a
+// decision OUTSIDE the guarded interfaces (sphere miss, TIR, a clip at a well-conditioned housing: residual flips <= ~1e-6 of
+// the rays, tests/test_parity_gpu.py); only the low-order bits of origin / direction of the FAST-evaluated rays differ.
+// TIR bumps are tallied per ray (above bit 0 of lutMiss) and reach the counters only when the ray finishes in this kernel.
+constexpr uint32_t kRetryDeadBit = 0x40000000u;   // lutMiss: bit 0 LUT miss, bits 1.. the ray's TIR tally, bit 30 retry-dead
+
+// Per-ray constants of camera_create_ray (zoic.cpp:1853-1855, 1891-1911): the sensor point, the exit-pupil LUT's scale and
+// translation, the (parabola) sine / cosine of the pupil rotation -- shared by phase A of the pass loop and by finish_dead_ray.  flags: bit 0 = outside the LUT (fenced UB), kRetryDeadBit = no retry of this ray can reach the rear element.
+struct RaySetup { float o0x, o0y, maxScale, translation, sn, cs; uint32_t flags; bool dead, lutEdge; };
+template <bool STRICT>
+__device__ __forceinline__ RaySetup setup_ray(const KolbTable &T, const float2 *lutLds, float sx, float sy)
+{
+    RaySetup r;
+    r.o0x = sx * T.halfSensor;  // zoic.cpp:1853-1854
+    r.o0y = sy * T.halfSensor;
+    r.maxScale = 0.0f; r.translation = 0.0f; r.sn = 0.0f; r.cs = 1.0f; r.flags = 0u; r.dead = false; r.lutEdge = false;
+    if (T.useLUT) {            // zoic.cpp:1891-1911: per-sample constants of the exit-pupil transform
+        float dist;
+        if constexpr (STRICT) dist = fabsf(ZOIC_SQRT_RN(r.o0x * r.o0x + r.o0y * r.o0y));
+        else dist = fsqrt_fast(r.o0x * r.o0x + r.o0y * r.o0y);
+        r.flags = lut_lookup_lds(lutLds, T.lutSize, dist, r.maxScale, r.translation) ? 0u : 1u;
+        // the only discontinuity of the lookup is the table's end (bin edges interpolate continuously)
+        r.lutEdge = fabsf(dist * 8.0f - static_cast<float>(T.lutSize - 1)) < T.bandLutBin;
+        // Outside the image circle the LUT entries are all zero (zoic.cpp:1403-1404 never grown): every try
+        // then shoots lens = (0,0).  With o0x != 0 and o0y != 0 the direction (0 - o0x, 0 - o0y, dirZ) is
+        // bit-identical for all 27 tries whatever the signs of the zeros, so one failed trace decides them all.
+        r.dead = (r.maxScale == 0.0f) && (r.translation == 0.0f) && (r.o0x != 0.0f) && (r.o0y != 0.0f);
+        if (!r.dead) {           // the rotation of (0,0) needs no angle: dead pixels skip atan2 + sin + cos
+            if constexpr (STRICT) {
+                const float theta = static_cast<float>(atan2(static_cast<double>(r.o0y), static_cast<double>(r.o0x)));
+                r.sn = fast_sin(theta);
+                r.cs = fast_cos(theta);
+            } else {
+                const float theta = atan2f(r.o0y, r.o0x);
+                r.sn = fast_sin_f32(theta);
+                r.cs = fast_cos_f32(theta);
+            }
+            if (T.retryOn) {
+                // retry-dead test (tables.hpp): can ANY retry of this ray reach the rear element?  The retries sample
+                // the disk of radius maxScale * |lens sample|max around the LUT centroid translated in BOTH components
+                // and rotated by the ray's (parabola) cos/sin; 1 % + 1e-4 of margin dwarfs every rounding involved.
+                const float k = T.useImage ? 1.4158f : 1.0023f;   // |lens sample| <= sqrt(2) (image) / 1.0011 (disk), x the rotation's 1.0011
+                const float ccx = r.translation * (r.cs - r.sn) - r.o0x * T.retryK1, ccy = r.translation * (r.sn + r.cs) - r.o0y * T.retryK1;
+                const float reach = (T.retryRho0 + dist * T.retrySpread + fabsf(r.maxScale) * k) * 1.01f + 1.0e-4f;
+                // |d.xy| of any retry <= |rotated, translated lens point| + |o.xy|: below retryMaxD the opposite cap is out of reach
+                const float dxyMax = fabsf(r.maxScale) * k + fabsf(r.translation) * 1.4158f + dist;
+                if (ccx * ccx + ccy * ccy > reach * reach && dxyMax <= T.retryMaxD) r.flags |= kRetryDeadBit;
+            }
+        }
+    }
+    return r;
+}
+
+// direction of a RETRY's lens sample (zoic.cpp:1932-1943 with the LUT, 1882-1884 without): shared by the pass loop and finish_dead_ray
+__device__ __forceinline__ V3 retry_direction(const KolbTable &T, V2 lens, float o0x, float o0y, float maxScale, float translation, float sn, float cs)
+{
+    if (!T.useLUT) return V3{(lens.x * T.rearAperture) - o0x, (lens.y * T.rearAperture) - o0y, T.dirZ};
+    lens.x *= maxScale; lens.y *= maxScale;
+    lens.x += translation;
+    lens.y += translation;              // retries translate BOTH components (zoic.cpp:1933)
+    const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
+    return V3{rx - o0x, ry - o0y, T.dirZ};
+}
+
+// finish_dead_ray: completes a retry-dead ray whose first try failed (tables.hpp KolbTable::retry*).  All 26 retries of such
+// a ray die at interface 0 -- they bump no counter and leave (o, d) untouched -- so the ray ends with weight 0, 26 tries and
+// the untouched state of its LAST retry (zoic.cpp:1951-1961): step the ray's retry stream over 25 draws, evaluate the lens
+// sample of the 26th, write the record.  ~800 instructions at full lane utilisation against 26 x ~95 in the draw loop at a
+// third of the lanes.  A draw of exactly (0.5, 0.5) makes the concentric-disk sample NaN (zoic.cpp:697-699), and a NaN ray
+// PASSES every comparison of the reference's trace: such a ray (probability 2e-15 per draw) is a success with NaN origin /
+// direction at that try -- reproduced here; returns true in that case (the caller counts it as a success).
+template <bool STRICT>
+__device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
+                                                const float4 *__restrict__ samples, const uint4 *__restrict__ states, uint64_t rayBase,
+                                                RayRecord *__restrict__ out, uint32_t idx)
+{
+    const float4 s = samples[idx];
+    const RaySetup rs = setup_ray<STRICT>(T, lutLds, s.x, s.y);
+    Rng rng;
+    if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+    else rng = rng_for_ray(T.seed, rayBase + idx);
+    // retries 1 ... 26 (zoic.cpp:1927-1947), branch-free and unrolled: one dependent chain of 52 xorshift steps that the
+    // scheduler interleaves with the (independent) set-up arithmetic above; the first draw at the disk's centre, if any, is
+    // remembered instead of leaving the loop (finish kernel 126 -> 113 us on C2; two rays per lane, to run two chains side
+    // by side, cost two waves of occupancy and measured 122)
+    uint32_t tries = static_cast<uint32_t>(kMaxTries) + 1u, a = 0, b = 0, hitTry = 0;
+#pragma unroll
+    for (uint32_t k = 1; k <= static_cast<uint32_t>(kMaxTries) + 1u; ++k) {
+        a = xor128(rng); b = xor128(rng);
+        // rng_unit(x) == 0.5f  <=>  x in [0x7fffffc0, 0x80000080]
+        const bool centre = ((a - 0x7fffffc0u) <= 0xc0u) & ((b - 0x7fffffc0u) <= 0xc0u);
+        hitTry = (centre && hitTry == 0u) ? k : hitTry;
+    }
+    const bool nanDraw = !T.useImage && hitTry != 0u;
+    if (nanDraw) tries = hitTry;
+    const float qnan = __builtin_bit_cast(float, 0x7fc00000u);
+    float w = nanDraw ? 1.0f : 0.0f;
+    if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
+    V3 o{rs.o0x, rs.o0y, T.originShift}, d{qnan, qnan, qnan};
+    if (nanDraw) o = V3{qnan, qnan, qnan};
+    else d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, rng_unit(a), rng_unit(b)), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+    store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
+                     1u | (tries << 1) | ((rs.flags & 1u) << 6));
+    return nanDraw;
+}
+
 
 // LDS per wave: the pool, 128 entries of three 16-byte pieces each, stored piece-major (three arrays of 128 float4: a
 // push or pop is three conflict-free ds_write_b128 / ds_read_b128), then the hand-over lists (128 ray indices each).
@@ -43,37 +184,54 @@ constexpr uint32_t kPoolListWords = 128;
 // bit 13 dead pixel, bit 14 retry-dead
 constexpr uint32_t kPoolTriesShift = 8, kPoolDeadBit = 1u << 13, kPoolRetryDeadBit = 1u << 14;
 
+// Register budgets: the FAST kernels are held to 80 VGPRs (6 waves per SIMD; the LDS pools admit 5-6 workgroups per CU), the
+// STRICT ones (f64 intermediates) to 128 = 4 waves per SIMD.
 #ifndef ZOIC_POOL_ATTR_FAST
 #define ZOIC_POOL_ATTR_FAST __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 #ifndef ZOIC_POOL_ATTR_STRICT
 #define ZOIC_POOL_ATTR_STRICT __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
+#ifndef ZOIC_POOL_PROBE_STRICT
+#define ZOIC_POOL_PROBE_STRICT 0   // the STRICT kernels spill when they also carry the probe of the next batch
+#endif
 
-template <bool STRICT, int NS, bool GUARD, bool LISTED, bool DEAD>
+__device__ __forceinline__ uint32_t mask_rank(unsigned long long m)   // exclusive prefix count of the lanes set in m
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+__device__ __forceinline__ bool mask_bit(unsigned long long m, uint32_t lane) { return ((m >> lane) & 1ull) != 0ull; }
+
+// IMAGE: the bokeh image is on AND its cell records are in LDS (tables.hpp; images up to 2048 rows x 4096 columns): every
+// lens sample is one ds_read_b128 + one global_load_dwordx4.  IMAGE = false covers the concentric-disk sampler and images
+// without records (16-ary pyramid / reference search through lens_sample's run-time branch).
+template <bool STRICT, int NS, bool GUARD, bool LISTED, bool DEAD, bool IMAGE>
 __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
                                                uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching)
 {
     static_assert(!(GUARD && STRICT) && !(LISTED && !STRICT), "GUARD is a FAST mode, LISTED the STRICT kernel behind it");
-    constexpr bool DEFER = GUARD || DEAD;   // rays may leave this kernel unfinished: TIR bumps are tallied per ray
+    constexpr bool DEFER = GUARD || DEAD;   // rays may leave the pass loop unfinished: TIR bumps are tallied per ray
+    constexpr bool PROBE = IMAGE && (!STRICT || ZOIC_POOL_PROBE_STRICT != 0);   // the next batch's first lens sample is requested a pass ahead
     constexpr uint32_t kOut = static_cast<uint32_t>(kMaxTries) + 1u;   // tries of a ray that ran out (zoic.cpp:1927: tries <= 25)
     uint32_t redoChunk = 0, redoChunksPerPart = 0;
     if constexpr (LISTED) {   // the work list's length is only known on the device
-        n = *ZOIC_KARG(redoCount);
+        n = *ZOIC_KARG(redoCount);   // <= samples of the launch, which is what the list was sized for
         if (n == 0u) return;
+        // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times over
         redoChunk = n > (1u << 20) ? 256u : 64u;
         const uint32_t totalChunks = (n + redoChunk - 1u) / redoChunk;
         if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed for it
         redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // LDS, once per workgroup: the 32 exit-pupil LUT pairs, then the bokeh row cell records (tables.hpp)
+    // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the two entries
+    // a sample interpolates -- then the bokeh row cell records (tables.hpp)
     if (threadIdx.x < kLutEntries) {
         zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
         zoicDynLds[2 * threadIdx.x + 1] = T.lutCentroidX[threadIdx.x];
     }
     const float *bokehLds = nullptr;
-    if (ldsWords > 0) {
+    if (IMAGE || ldsWords > 0) {
         for (uint32_t i = threadIdx.x; i < ldsWords; i += kRefillBlock) zoicDynLds[kLutLdsWords + i] = __builtin_bit_cast(float, B.rowCells[i]);
         bokehLds = zoicDynLds + kLutLdsWords;
     }
@@ -88,56 +246,116 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     uint32_t *deadLds = lists + (GUARD ? kPoolListWords : 0u);    // DEAD: retry-dead rays whose first try failed
     uint32_t poolCnt = 0, unsureCnt = 0, deadCnt = 0;             // wave-uniform
 
+    const auto sample_lens = [&](float u, float v) {
+        if constexpr (IMAGE) return bokeh_sample_cells<STRICT>(B, bokehLds, T.bokehW, T.bokehH, u, v);
+        else return lens_sample<STRICT>(T, B, nullptr, u, v);
+    };
+
     // fresh work: chunks of consecutive samples claimed from the partition cursors (work_cursor.hpp); [next, end) is what is
-    // left of the wave's chunk, `pre` the batch requested one pass ahead
+    // left of the wave's chunk.  Two batches are in flight: b1 runs next -- its samples have arrived and (PROBE) the column
+    // cell record of its FIRST lens sample is already requested (zoic.cpp:1870) -- and b2, requested one pass before that.
     uint32_t next = 0, end = 0, part = blockIdx.x % kCursorParts, partsTried = 0;
-    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t preIdx = 0, preBase = 0, preCnt = 0;
-    bool havePre = false;
-    const auto request_batch = [&]() {
-        havePre = false;
-        if (next >= end) {
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    uint32_t idx1 = 0, idx2 = 0, base1 = 0, base2 = 0, cnt1 = 0, cnt2 = 0;   // idx: LISTED only
+    bool have1 = false, have2 = false;
+    CellProbe probe{make_uint4(0u, 0u, 0u, 0u), 0, 0u};
+    const auto request_batch = [&]() {   // -> b2
+        have2 = false;
+        if (next >= end) {   // claim the next chunk: one atomic per chunkRays samples per wave
             const uint32_t cr = LISTED ? redoChunk : ZOIC_KARG(chunkRays), cpp = LISTED ? redoChunksPerPart : ZOIC_KARG(chunksPerPart);
             if (!claim_chunk(ZOIC_KARG(workCursor), lane, part, partsTried, cr, cpp, n, next, end)) return;
         }
-        preBase = next;
-        preCnt = (end - next < 64u) ? end - next : 64u;
-        const uint32_t wi = (lane < preCnt) ? next + lane : next;
-        if constexpr (LISTED) { preIdx = ZOIC_KARG(redoList)[wi]; pre = samples[preIdx]; }
-        else pre = samples[wi];
-        next += preCnt;
-        havePre = true;
+        base2 = next;
+        cnt2 = (end - next < 64u) ? end - next : 64u;
+        const uint32_t wi = (lane < cnt2) ? next + lane : next;
+        if constexpr (LISTED) { idx2 = ZOIC_KARG(redoList)[wi]; s2 = samples[idx2]; }
+        else s2 = samples[wi];
+        next += cnt2;
+        have2 = true;
+    };
+    const auto advance_batches = [&]() {   // b1 <- b2 (+ its probe), b2 <- the next request
+        s1 = s2; idx1 = idx2; base1 = base2; cnt1 = cnt2; have1 = have2;
+        if constexpr (PROBE) { if (have1) probe = bokeh_cells_issue(B, bokehLds, T.bokehH, s1.z, s1.w); }
+        if (have1) request_batch();
     };
     request_batch();
+    advance_batches();
 
     uint32_t succ = 0, vign = 0, tir = 0;   // wave totals (SGPRs)
     uint32_t tirAcc = 0;                    // DEFER: per-lane sum of the TIR tallies of the rays this lane finished
 
-    const bool memoryPhasesFirst = T.useImage != 0;
+    // Wave priority (s_setprio; measured, same box): with the bokeh image on, waves wait on the sampler's LDS -> global chain,
+    // and letting the waves that are in their memory phases issue first gets those loads out earlier; without it the launch is
+    // compute-dense and the waves inside the trace go first.
+    constexpr bool memoryPhasesFirst = IMAGE;
     for (;;) {
-        const bool drain = !havePre;                                        // no fresh sample left for this wave
+        const bool drain = !have1;                                          // no fresh sample left for this wave
         const bool fromPool = poolCnt >= 64u || (drain && poolCnt != 0u);
         if (!fromPool && drain) break;
         if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(1);
         FastSurfaceTable fsurf = nullptr;
-        if constexpr (GUARD && (ZOIC_GUARD_PIN != 0)) fsurf = launder_table(kernarg_fast_surfaces());
+        if constexpr (GUARD && (ZOIC_GUARD_PIN != 0)) fsurf = launder_table(kernarg_fast_surfaces());   // keeps the table's s_loads at their use (fast_optics.hpp)
         else if constexpr (!STRICT) fsurf = kernarg_fast_surfaces();
         (void)fsurf;
 
         // ---- the pass's 64 rays: a fresh batch (phase A) or 64 pooled rays (phase B) -------------------------------------
-        bool active, fresh, dead, unsure = false;
+        bool active, dead, unsure = false;
         uint32_t idx, tries, lutMiss;   // lutMiss: bit 0 outside the LUT, bits 1.. the TIR tally, kRetryDeadBit
-        float o0x, o0y, maxScale, translation, sn, cs, u, v;
+        float o0x, o0y, maxScale, translation, sn, cs;
         Rng rng{1, 2, 3, 4};
+        V3 o, d{0.0f, 0.0f, 1.0f};
+        bool cand = false, finiteSample = true, searching;
+        bool toFinish = false;   // a retry-dead ray whose first try has failed -> the dead list
+        // does (o, d) clear interface 0?  near0: too close to call (GUARD)
+        const auto clears_rear = [&](const V3 &oo, const V3 &dd, bool &near0) {
+            if constexpr (STRICT) {
+                near0 = false;
+                bool inRange;
+                bool p = interface0_clear_strict_lean(T, oo, dd, inRange);
+                if (__builtin_expect(!inRange, 0)) p = interface0_clear_strict(T, oo, dd);   // never seen: guarded roots
+                return p;
+            }
+            else return interface0_clear_fast<GUARD>(load_surface<false>(fsurf, 0), oo, dd, near0);
+        };
         if (!fromPool) {
-            active = lane < preCnt;
-            idx = LISTED ? preIdx : preBase + lane;
-            const RaySetup rs = setup_ray<STRICT>(T, lutLds, pre.x, pre.y);
+            // phase A: set 64 fresh rays up and run the search's FIRST step for all of them (zoic.cpp:1853-1925)
+            active = lane < cnt1;
+            idx = LISTED ? idx1 : base1 + lane;
+            const RaySetup rs = setup_ray<STRICT>(T, lutLds, s1.x, s1.y);
             o0x = rs.o0x; o0y = rs.o0y; maxScale = rs.maxScale; translation = rs.translation; sn = rs.sn; cs = rs.cs;
             lutMiss = rs.flags; dead = rs.dead;
             if constexpr (GUARD) unsure = active && T.useLUT && rs.lutEdge;
-            u = pre.z; v = pre.w;
-            tries = 0; fresh = true;
+            tries = 0;
+            o = V3{o0x, o0y, T.originShift};
+            searching = GUARD ? (active && !unsure) : active;
+            const float u = s1.z, v = s1.w;
+            // dead pixel (outside the image circle, LUT entries zero): whatever finite point the sampler returns, the direction
+            // is (0 - o.x, 0 - o.y, dirZ); samples in [0,1)^2 off the disk mapping's 0/0 centre need no sampler
+            const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
+            V2 lens;
+            if constexpr (PROBE) lens = bokeh_cells_finish<STRICT>(B, T.bokehW, T.bokehH, v, probe);
+            else lens = sample_lens(u, v);
+            if (dead && plainSample) lens = V2{0.0f, 0.0f};
+            finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
+            if (!T.useLUT) {                    // zoic.cpp:1873-1877
+                d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+            } else {                            // zoic.cpp:1913-1924: the first sample is translated in x only
+                lens.x *= maxScale; lens.y *= maxScale;
+                lens.x += translation;
+                const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
+                d = V3{rx - o.x, ry - o.y, T.dirZ};
+            }
+            bool near0;
+            const bool pass0 = clears_rear(o, d, near0);
+            if (searching) {
+                if (GUARD && near0) { unsure = true; searching = false; }   // too close to call: no decision is taken here
+                else if (pass0) { cand = true; searching = false; }
+                else {
+                    // a clip at interface 0 bumps no TIR counter and leaves (o, d) untouched: for a dead pixel all 27 tries are this one
+                    if (dead && finiteSample) { tries = kOut; searching = false; }
+                    else if (DEAD && (lutMiss & kRetryDeadBit) != 0u) { toFinish = true; searching = false; }   // no retry can succeed
+                }
+            }
         } else {
             const uint32_t cnt = poolCnt < 64u ? poolCnt : 64u;
             poolCnt -= cnt;
@@ -152,75 +370,46 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             tries = (packed >> kPoolTriesShift) & 31u;
             dead = (packed & kPoolDeadBit) != 0u;
             lutMiss = (packed & 0x7fu) | ((packed & kPoolRetryDeadBit) ? kRetryDeadBit : 0u);
-            u = 0.0f; v = 0.0f; fresh = false;
+            o = V3{o0x, o0y, T.originShift};
+            searching = active;
         }
 
-        // ---- candidate search: draw lens samples until one clears the rear element's housing ---------------------------------
-        // (zoic.cpp:1870-1925 first sample, 1927-1947 retries; tries and the retry stream advance exactly as in the reference's
-        // loop; the loop is wave-uniform and goes on while enough lanes are looking to be worth the others' wait)
-        V3 o{o0x, o0y, T.originShift}, d{0.0f, 0.0f, 1.0f};
-        bool cand = false, finiteSample = true;
-        bool searching = GUARD ? (active && !unsure) : active;
-        bool toFinish = false;   // a retry-dead ray whose first try has failed -> the dead list
+        // ---- candidate search: RETRIES draw lens samples until one clears the rear element's housing (zoic.cpp:1927-1947) ----
+        // Most rejected tries die at interface 0 (94 % of TESSAR retries, 91 % of wide-open PETZVAL retries, half of DOUBLE_GAUSS
+        // retries); testing it alone costs a tenth of a whole try, so a lane keeps drawing -- tries and the ray's retry stream
+        // advance exactly as in the reference's loop -- until a sample survives or it runs out of tries; the full trace then runs
+        // once for the survivors.  The loop is wave-uniform: it goes on while enough lanes are looking to be worth the others'
+        // wait (any lane, once the wave has no fresh work left).
         for (;;) {
-            if (searching) {
-                const bool first = fresh;
-                if (!first) {                       // retry: new lens sample from the ray's own stream, zoic.cpp:1930
-                    if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
-                        const uint4 *states = ZOIC_KARG(rngStates);
-                        if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
-                        else rng = rng_for_ray(kernarg_field<uint32_t, offsetof(RefillArgs, T) + offsetof(KolbTable, seed)>(), ZOIC_KARG(rayBase) + idx);
-                    }
-                    u = rng_unit(xor128(rng));
-                    v = rng_unit(xor128(rng));
-                    ++tries;
-                }
-                fresh = false;
-                // dead pixel (outside the image circle, LUT entries zero): whatever finite point the sampler returns, the
-                // direction is (0 - o.x, 0 - o.y, dirZ); samples in [0,1)^2 off the disk mapping's 0/0 centre skip the sampler
-                const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
-                const bool skipSampler = first && dead && plainSample;
-                V2 lens{0.0f, 0.0f};
-                if (!skipSampler) lens = lens_sample<STRICT>(T, B, bokehLds, u, v);
-                finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
-                if (!T.useLUT) {                    // zoic.cpp:1873-1877 / 1882-1884
-                    d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
-                } else {                            // zoic.cpp:1913-1924 / 1932-1943
-                    lens.x *= maxScale; lens.y *= maxScale;
-                    lens.x += translation;
-                    if (!first) lens.y += translation;  // retries translate BOTH components (zoic.cpp:1933)
-                    const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
-                    d = V3{rx - o.x, ry - o.y, T.dirZ};
-                }
-                bool pass0, near0 = false;
-                if constexpr (STRICT) {
-                    bool inRange;
-                    pass0 = interface0_clear_strict_lean(T, o, d, inRange);
-                    if (__builtin_expect(!inRange, 0)) pass0 = interface0_clear_strict(T, o, d);   // never seen: guarded roots
-                }
-                else if constexpr (GUARD) pass0 = interface0_clear_fast_guard(load_surface<false>(fsurf, 0), o, d, near0);
-                else pass0 = interface0_clear_fast(load_surface<false>(fsurf, 0), o, d);
-                if (GUARD && near0) { unsure = true; searching = false; }   // too close to call: no decision is taken here
-                else if (pass0) { cand = true; searching = false; }
-                else {
-                    // a clip at interface 0 bumps no TIR counter and leaves (o, d) untouched: for a dead pixel all 27 tries are this one
-                    if (first && dead && finiteSample) tries = kOut;
-                    if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
-                    else if (DEAD && first && (lutMiss & kRetryDeadBit) != 0u) { toFinish = true; searching = false; }   // no retry can succeed
-                }
-            }
             const uint32_t looking = static_cast<uint32_t>(__popcll(__ballot(searching)));
             if (looking < (drain ? 1u : minSearching)) break;
+            if (searching) {
+                if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
+                    const uint4 *states = ZOIC_KARG(rngStates);
+                    if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+                    else rng = rng_for_ray(kernarg_field<uint32_t, offsetof(KolbKernelArgs, T) + offsetof(KolbTable, seed)>(), ZOIC_KARG(rayBase) + idx);
+                }
+                const float u = rng_unit(xor128(rng));   // zoic.cpp:1930
+                const float v = rng_unit(xor128(rng));
+                ++tries;
+                d = retry_direction(T, sample_lens(u, v), o0x, o0y, maxScale, translation, sn, cs);   // zoic.cpp:1932-1943: BOTH components translated
+                bool near0;
+                const bool pass0 = clears_rear(o, d, near0);
+                if (GUARD && near0) { unsure = true; searching = false; }
+                else if (pass0) { cand = true; searching = false; }
+                else if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
+            }
         }
 
-        // ---- request the batch after this one: issued here so that the sampler's dependent load above never waits for it ----
-        if (!fromPool) request_batch();
+        // ---- the fresh batches move up; issued here so that the sampler's dependent load above never waits for these loads ------
+        if (!fromPool) advance_batches();
 
         // ---- one full trace for every lane that holds a candidate -------------------------------------------------------------
         bool ok = false;
         const V3 oStart = o, dStart = d;
         const bool firstTry = tries == 0;
-        if (__ballot(cand) != 0ull) {
+        const unsigned long long candMask = __ballot(cand);
+        if (candMask != 0ull) {
             if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
             uint32_t tirTry = 0;   // 0/1: this try ended in total internal reflection
             if constexpr (NS > 0) {
@@ -230,9 +419,13 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                     if (__builtin_expect(__ballot(cand && oor) != 0ull, 0)) {   // never seen: a root left the lean sequences' verified range
                         if (cand && oor) { o = oStart; d = dStart; tirTry = 0; ok = trace_lens_strict(T, o, d, tirTry); }
                     }
+                } else {
+                    unsigned long long tirMask, unsureMask;
+                    const unsigned long long alive = trace_lens_fast_pred<NS, GUARD>(fsurf, o, d, candMask, tirMask, unsureMask);
+                    ok = mask_bit(alive, lane);
+                    tirTry = mask_bit(tirMask, lane) ? 1u : 0u;
+                    if constexpr (GUARD) unsure |= mask_bit(unsureMask, lane);
                 }
-                else if constexpr (GUARD) { bool u2 = false; ok = trace_lens_fast_pred<NS, true>(fsurf, o, d, tirTry, cand, &u2); unsure |= cand && u2; }
-                else ok = trace_lens_fast_pred<NS>(fsurf, o, d, tirTry, cand);
             } else if (cand) {
                 if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
                 else if constexpr (GUARD) { bool u2 = false; ok = trace_lens_fast_rolled(T, o, d, tirTry, &u2); unsure |= u2; }
@@ -241,6 +434,8 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             const bool shortcut = cand && !ok && firstTry && dead && finiteSample && !(GUARD && unsure);
             // the shortcut stands for 26 more identical failures: account for their TIR bumps as well
             if constexpr (DEFER) {
+                // a dropped ray must leave no trace in the counters (the kernel that picks it up counts it): TIR bumps are
+                // tallied per ray, above bit 0 of lutMiss, and reach the wave total only when the ray finishes here
                 if (!unsure) lutMiss += (tirTry << 1) + (shortcut ? (tirTry * kOut) << 1 : 0u);
             } else {
                 tir += static_cast<uint32_t>(__popcll(__ballot(tirTry != 0u))) + kOut * static_cast<uint32_t>(__popcll(__ballot(shortcut && tirTry != 0u)));
@@ -260,6 +455,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         }
         if (!memoryPhasesFirst) __builtin_amdgcn_s_setprio(0);
         // a lane that ran out at interface 0 hands out the untouched (o, d) of its last sample -- the reference's partial state
+        // (the predicated trace scribbles over the registers of lanes that ride along)
         if (!cand) { o = oStart; d = dStart; }
 
         // ---- finished rays: counters + record; hand-overs; everything else goes (back) to the pool --------------------------
@@ -283,16 +479,14 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         if constexpr (GUARD) {
             const unsigned long long m = __ballot(dropU);
             if (m != 0ull) {
-                const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-                if (dropU) unsureLds[unsureCnt + r] = idx;
+                if (dropU) unsureLds[unsureCnt + mask_rank(m)] = idx;
                 unsureCnt += static_cast<uint32_t>(__popcll(m));
             }
         }
         if constexpr (DEAD) {
             const unsigned long long m = __ballot(dropF);
             if (m != 0ull) {
-                const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-                if (dropF) deadLds[deadCnt + r] = idx;
+                if (dropF) deadLds[deadCnt + mask_rank(m)] = idx;
                 deadCnt += static_cast<uint32_t>(__popcll(m));
             }
         }
@@ -300,9 +494,8 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             const bool keep = active && !finished && !dropU && !dropF;
             const unsigned long long m = __ballot(keep);
             if (m != 0ull) {
-                const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
                 if (keep) {
-                    const uint32_t slot = poolCnt + r;
+                    const uint32_t slot = poolCnt + mask_rank(m);
                     const uint32_t packed = (lutMiss & 0x7fu) | (tries << kPoolTriesShift) | (dead ? kPoolDeadBit : 0u) |
                                             ((lutMiss & kRetryDeadBit) ? kPoolRetryDeadBit : 0u);
                     pool0[slot] = make_float4(__builtin_bit_cast(float, idx), o0x, o0y, __builtin_bit_cast(float, packed));
@@ -312,9 +505,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 poolCnt += static_cast<uint32_t>(__popcll(m));
             }
         }
-        // ---- hand-over lists: flushed in whole batches ---------------------------------------------------------------------
+        // ---- hand-over lists: emptied in whole batches ---------------------------------------------------------------------
         if constexpr (GUARD) {
-            if (unsureCnt >= 64u) {   // one atomic reserves exactly the entries written
+            if (unsureCnt >= 64u) {   // one atomic reserves exactly the entries written: no holes in the work list
                 uint32_t at = 0;
                 if (lane == 0) at = atomicAdd(ZOIC_KARG(redoCount), unsureCnt);
                 at = __builtin_amdgcn_readfirstlane(at);
@@ -368,15 +561,16 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     }
 }
 
+// the precisions / roles are separate kernels so that each can carry its own register-budget attributes
 #define ZOIC_POOL_PARAMS const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, \
         uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,        \
         uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList,             \
-        unsigned int *__restrict__ redoCount, uint8_t *__restrict__ deadMap
+        unsigned int *__restrict__ redoCount
 #define ZOIC_POOL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_, LISTED_)                                                               \
-    template <int NS, bool DEAD>                                                                                             \
+    template <int NS, bool DEAD, bool IMAGE>                                                                                 \
     __global__ __launch_bounds__(kRefillBlock) ATTR_ void NAME_(ZOIC_POOL_PARAMS)                                             \
     {                                                                                                                        \
-        kolb_pool_body<STRICT_, NS, GUARD_, LISTED_, DEAD>(T, B, samples, n, out, ldsWords, minSearching);                    \
+        kolb_pool_body<STRICT_, NS, GUARD_, LISTED_, DEAD, IMAGE>(T, B, samples, n, out, ldsWords, minSearching);             \
     }
 ZOIC_POOL_KERNEL(kolb_pool_strict_kernel, ZOIC_POOL_ATTR_STRICT, true, false, false)          // STRICT, whole batch
 ZOIC_POOL_KERNEL(kolb_pool_strict_listed_kernel, ZOIC_POOL_ATTR_STRICT, true, false, true)    // STRICT over the work list of the GUARD kernel
@@ -385,8 +579,9 @@ ZOIC_POOL_KERNEL(kolb_pool_guard_kernel, ZOIC_POOL_ATTR_FAST, false, true, false
 #undef ZOIC_POOL_KERNEL
 #undef ZOIC_POOL_PARAMS
 
-// mode: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked.  d_scratch: the work list of mode 1 (one dword per sample of a launch)
-template <bool DEAD>
+// mode: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked.  d_scratch: the work list of mode 1 (kolb_scratch_dwords():
+// one dword per sample of a launch)
+template <bool DEAD, bool IMAGE>
 int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                           uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                           int mode, uint32_t *d_scratch, void *stream)
@@ -403,18 +598,16 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
         const WorkGrain grain = work_grain(m, mode == 0 ? 256u : 512u);
         const uint32_t chunkRays = grain.chunkRays, chunksPerPart = grain.chunksPerPart;
         RayRecord *o = out + done;
-        static const uint32_t minSearching = [] { const char *e = std::getenv("ZOIC_MIN_SEARCHING"); return e ? static_cast<uint32_t>(std::atoi(e)) : kMinSearching; }();
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
         const uint4 *rp = d_rng ? reinterpret_cast<const uint4 *>(d_rng) + done : nullptr;
-        const uint32_t ldsWords = (table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
+        const uint32_t ldsWords = IMAGE ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;   // bokeh row cell records: 4 KB at 256 rows, 32 KB at the 2048-row limit
         const auto lds_bytes = [&](bool guard) {
             return static_cast<size_t>(ldsWords + kLutLdsWords + kWavesPerBlock * (kPoolWaveWords + (guard ? kPoolListWords : 0u) + (DEAD ? kPoolListWords : 0u))) * sizeof(float);
         };
         unsigned int *redoCount = d_workCursor + kRedoCountOffset, *redoCursor = d_workCursor + kRedoCursorOffset;
 #define ZOIC_LAUNCH_POOL(KERNEL_, NS_, CURSOR_, GUARD_)                                                                          \
-    hipLaunchKernelGGL((KERNEL_<NS_, DEAD>), dim3(grid), dim3(kRefillBlock), lds_bytes(GUARD_), st, table, bokeh, sp, rp, rayBase + done, \
-                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, minSearching, d_redoList, redoCount, \
-                       static_cast<uint8_t *>(nullptr))
+    hipLaunchKernelGGL((KERNEL_<NS_, DEAD, IMAGE>), dim3(grid), dim3(kRefillBlock), lds_bytes(GUARD_), st, table, bokeh, sp, rp, rayBase + done, \
+                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, kMinSearching, d_redoList, redoCount)
 #define ZOIC_LAUNCH_POOL_BY_COUNT(KERNEL_, CURSOR_, GUARD_)                                                                      \
     switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                   \
     case 7: ZOIC_LAUNCH_POOL(KERNEL_, 7, CURSOR_, GUARD_); break;                                                               \
@@ -440,6 +633,12 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
         if (e != hipSuccess) return static_cast<int>(e);
     }
     return 0;
+}
+
+// cell records usable by the IMAGE kernels: present and small enough for LDS (tables.hpp)
+inline bool kolb_image_cells(const KolbTable &table, const BokehTables &bokeh)
+{
+    return table.useImage && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240;
 }
 
 }  // namespace zoic

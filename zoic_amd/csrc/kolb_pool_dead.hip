@@ -9,7 +9,9 @@ int launch_kolb_pool_dead(const KolbTable &table, const BokehTables &bokeh, cons
                           uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
                           int mode, uint32_t *d_scratch, void *stream)
 {
-    return launch_kolb_pool_impl<true>(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
+    if (kolb_image_cells(table, bokeh))
+        return launch_kolb_pool_impl<true, true>(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
+    return launch_kolb_pool_impl<true, false>(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
 }
 
 }  // namespace zoic

@@ -257,14 +257,18 @@ void LensSystem::fill_surfaces(KolbTable &t) const
         s.invRadius = 1.0f / r.radius;
         FastSurface &q = t.fsurf[i];
         q = FastSurface{};
-        q.center = s.center; q.radius2 = s.radius2; q.sign = s.sign; q.housing2 = s.housing2; q.invRadius = s.invRadius;
+        q.center = s.center; q.radius2 = s.radius2; q.sign = s.sign; q.housing2 = s.housing2;
         q.eta = s.eta;
-        const double eta = s.eta, invR = 1.0 / static_cast<double>(r.radius);
-        q.etaInvAbsR = static_cast<float>(eta * std::fabs(invR));
-        q.e2InvR2 = static_cast<float>(eta * eta * invR * invR);
-        q.oneMinusEta2 = static_cast<float>(1.0 - eta * eta);
+        const double eta = s.eta, R = static_cast<double>(r.radius);
+        q.qOffset = static_cast<float>((1.0 - eta * eta) * R * R / (eta * eta));
+        q.krScale = static_cast<float>(eta / (std::fabs(R) * R));
         const float relBand = eps * std::fabs(r.radius) / std::sqrt(s.housing2);   // relative to housing2
-        q.bandHousing = (relBand > kGuardMinRelBand) ? guardScale * relBand * s.housing2 : 0.0f;
+        const float band = (relBand > kGuardMinRelBand) ? guardScale * relBand * s.housing2 : 0.0f;
+        q.housingLo = q.housingHi = s.housing2;
+        if (band > 0.0f) {   // outward rounding: (housingLo, housingHi] contains every h2 with |h2 - housing2| < band
+            q.housingLo = std::nextafterf(s.housing2 - band, -INFINITY);
+            q.housingHi = std::nextafterf(s.housing2 + band, INFINITY);
+        }
     }
 }
 

@@ -43,16 +43,15 @@ struct FastSurface {
     float radius2;       // R^2
     float sign;          // sgn(R)
     float housing2;      // clip limit on x^2+y^2 (same f32 as Surface::housing2)
-    float invRadius;     // 1/R
     float eta;           // n1/n2
-    float etaInvAbsR;    // eta/|R|          : eta*cos(i) = thc * etaInvAbsR
-    float e2InvR2;       // eta^2/R^2        : 1 - cs2 = oneMinusEta2 + e2InvR2 * thc^2
-    float oneMinusEta2;  // 1 - eta^2
-    // Guard bands of the decision-safe FAST mode (kolb_refill.hip): a FAST decision is trusted only when its operands are
-    // further from the decision boundary than the band; otherwise the ray is handed to the STRICT kernel.
-    float bandHousing;   // > 0 on guarded (ill-conditioned) interfaces only: |h^2 - housing2| < bandHousing means the
-                         // housing / stop clip (zoic.cpp:1111-1117) is too close to call in FAST arithmetic; 0: not guarded
-    float pad0, pad1;
+    float qOffset;       // (1 - eta^2) R^2 / eta^2 : q = thc^2 + qOffset, 1 - cs2 = (eta/R)^2 q, TIR <=> q < 0
+    float krScale;       // eta / (|R| R)           : u' = eta u + krScale (thc - sqrt(q)) (c - hit)
+    // Guard band of the decision-safe FAST mode: a FAST clip decision is trusted only when h^2 lies outside
+    // (housingLo, housingHi]; otherwise the ray is handed to the STRICT kernel.  housing2 -/+ the band, rounded outwards, on
+    // guarded (ill-conditioned) interfaces -- in practice the stop (zoic.cpp:1111-1117) -- and == housing2 everywhere else:
+    // the guarded clip is two compares, clipped-or-unsure = h^2 > housingLo, unsure = that and !(h^2 > housingHi)
+    float housingLo, housingHi;
+    float pad0, pad1, pad2;
 };
 
 struct KolbTable {
