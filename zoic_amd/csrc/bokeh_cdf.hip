@@ -145,14 +145,18 @@ __global__ void build_cells_kernel(const float *__restrict__ cdfRow, const int32
             const int half = len >> 1;
             if (cdf[hi + half] < upper) { hi += half + 1; len -= half + 1; } else len = half;
         }
+        // thresholds = the first two DISTINCT CDF values above the cell's lower edge: a run of equal values (the zero-luminance
+        // tail of every CDF) is ONE decision for std::upper_bound -- u < value: before the run, else: after all of it
         const float inf = __builtin_inff();
-        const float a = lo < n ? cdf[lo] : inf, b = lo + 1 < n ? cdf[lo + 1] : inf;
-        uint32_t id[3];
-        for (int k = 0; k < 3; ++k) { const int e = lo + k < n ? lo + k : n - 1; id[k] = static_cast<uint32_t>(idx[e] - idxBase) & 0xffffu; }
+        const float a = lo < n ? cdf[lo] : inf;
+        const int j = lo < n ? lo + upper_bound_idx(cdf + lo, n - lo, a) : n;      // first entry > a
+        const float b = j < n ? cdf[j] : inf;
+        const int k = j < n ? j + upper_bound_idx(cdf + j, n - j, b) : n;          // first entry > b
+        const int e0 = lo < n ? lo : n - 1, e1 = j < n ? j : n - 1, e2 = k < n ? k : n - 1;
         uint4 out;
         out.x = __builtin_bit_cast(uint32_t, a); out.y = __builtin_bit_cast(uint32_t, b);
-        out.z = id[0] | (id[1] << 16);
-        out.w = id[2] | ((hi - lo > 2) ? 0x80000000u : 0u);
+        out.z = (static_cast<uint32_t>(idx[e0] - idxBase) & 0xffffu) | ((static_cast<uint32_t>(idx[e1] - idxBase) & 0xffffu) << 16);
+        out.w = (static_cast<uint32_t>(idx[e2] - idxBase) & 0xffffu) | ((k < hi) ? 0x80000000u : 0u);   // a third distinct value inside the cell
         reinterpret_cast<uint4 *>(rec)[c] = out;
         bnd[c] = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
     }

@@ -435,14 +435,19 @@ zoic_status upload_bokeh(zoic_camera *cam)
                         while (lo < n && cdf[lo] <= lower) ++lo;   // lo = #{cdf <= lower}
                         if (hi < lo) hi = lo;
                         while (hi < n && cdf[hi] < upper) ++hi;    // hi = #{cdf <  upper}
+                        // the first two DISTINCT values above the lower edge (a run of equal values is one decision), as build_cells_kernel
                         const float inf = INFINITY;
-                        const float a = lo < n ? cdf[lo] : inf, b = lo + 1 < n ? cdf[lo + 1] : inf;
+                        const float a = lo < n ? cdf[lo] : inf;
+                        const int j = lo < n ? lo + upper_bound_idx(cdf + lo, n - lo, a) : n;
+                        const float b = j < n ? cdf[j] : inf;
+                        const int k = j < n ? j + upper_bound_idx(cdf + j, n - j, b) : n;
+                        const int e[3] = {std::min(lo, n - 1), std::min(j, n - 1), std::min(k, n - 1)};
                         uint32_t id[3];
-                        for (int k = 0; k < 3; ++k) id[k] = static_cast<uint32_t>(idx[std::min(lo + k, n - 1)] - idxBase) & 0xffffu;
+                        for (int q = 0; q < 3; ++q) id[q] = static_cast<uint32_t>(idx[e[q]] - idxBase) & 0xffffu;
                         std::memcpy(rec + 0, &a, 4);
                         std::memcpy(rec + 1, &b, 4);
                         rec[2] = id[0] | (id[1] << 16);
-                        rec[3] = id[2] | ((hi - lo > 2) ? 0x80000000u : 0u);
+                        rec[3] = id[2] | ((k < hi) ? 0x80000000u : 0u);
                         *bnd = static_cast<uint32_t>(lo) | (static_cast<uint32_t>(hi) << 16);
                     }
                 };

@@ -70,6 +70,9 @@ __device__ __forceinline__ float atan2_f32(float y, float x)
 #ifndef ZOIC_GUARD_PIN
 #define ZOIC_GUARD_PIN 1
 #endif
+#ifndef ZOIC_TRACE_PREFETCH
+#define ZOIC_TRACE_PREFETCH 1
+#endif
 typedef const FastSurface __attribute__((address_space(4))) *FastSurfaceTable;
 // The KolbTable is the FIRST kernel argument of every Kolb kernel (offset 0 of the kernarg segment): its FastSurface array
 // is addressed from the kernarg base.  (Deriving the pointer from &T instead makes the by-value argument's address escape
@@ -94,6 +97,13 @@ __device__ __forceinline__ FastSurface load_surface(FastSurfaceTable t, int i)
     S.housingLo = t[i].housingLo; S.housingHi = t[i].housingHi;
     S.pad0 = S.pad1 = S.pad2 = 0.0f;
     return S;
+}
+
+// every word of S is in its SGPR from here on (the compiler puts the s_waitcnt of the scalar loads in front of this)
+__device__ __forceinline__ void surface_arrived(const FastSurface &S)
+{
+    asm volatile("" : : "s"(S.center), "s"(S.radius2), "s"(S.sign), "s"(S.housing2), "s"(S.eta), "s"(S.qOffset), "s"(S.krScale),
+                 "s"(S.housingLo), "s"(S.housingHi));
 }
 
 __device__ __forceinline__ float uniform_f32(float v)
@@ -234,10 +244,19 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
     V3 u{d.x * inv, d.y * inv, d.z * inv};
     float oAxis2 = o.x * o.x + o.y * o.y;
     unsigned long long alive = alive0, tirSeen = 0ull, unsure = 0ull;   // alive0: lanes without a candidate ride along dead
+    // The table words of interface i + 1 are requested BEFORE interface i is evaluated (scalar loads return out of order, so
+    // the only wait there is is lgkmcnt(0): `surface_arrived` takes it at the end of interface i, a whole interface -- ~30 VALU --
+    // after the request; the sched_barrier keeps the scheduler from sinking the request towards its use).  Loading at the use
+    // instead stalls every wave for a scalar-cache round trip per interface.
+    FastSurface S = load_surface<true>(surf, 0);
+    if constexpr (ZOIC_TRACE_PREFETCH != 0) surface_arrived(S);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (i >= 2 && (i & 1) == 0 && alive == 0ull) break;   // wave-uniform early out, every 2nd interface
-        const FastSurface S = load_surface<GUARD && (ZOIC_GUARD_PIN != 0)>(surf, i);
+        FastSurface Sn = S;
+        if constexpr (ZOIC_TRACE_PREFETCH != 0) {
+            if (i + 1 < NS) { Sn = load_surface<true>(surf, i + 1); __builtin_amdgcn_sched_barrier(0); }   // the request goes out HERE
+        }
         const FastHit h = fast_hit(S, o, oAxis2, u);
         unsigned long long clipped = __ballot(h.miss);
         if constexpr (GUARD) {
@@ -253,6 +272,8 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
         alive &= ~clipped;
         tirSeen |= alive & tirHere;                      // counted only by rays that reached the refraction
         alive &= ~tirHere;
+        if constexpr (ZOIC_TRACE_PREFETCH != 0) { if (i + 1 < NS) surface_arrived(Sn); S = Sn; }   // ... and is waited for here, in the same block
+        else if (i + 1 < NS) S = load_surface<GUARD && (ZOIC_GUARD_PIN != 0)>(surf, i + 1);
     }
     tirMask = tirSeen;
     unsureMask = unsure;

@@ -16,10 +16,10 @@ namespace zoic {
 constexpr int kRefillBlock = 256;
 constexpr int kWavesPerBlock = kRefillBlock / 64;
 constexpr uint32_t kLutLdsWords = 2 * kLutEntries;  // (maxScale, centroid.x) pairs at the start of the dynamic LDS
-constexpr uint32_t kGuardLdsWords = 192;  // decision-safe kernel, per wave: 128 staged ray indices + 64 per-lane TIR tallies
-constexpr uint32_t kDeadLdsWords = 320;   // DEAD kernels: + 128 staged retry-dead rays
-constexpr uint32_t kFinishBlock = 1024;   // finish kernel: map bytes (= rays) a wave compacts at a time
-constexpr uint32_t kMinSearching = 16;  // the candidate search goes on while at least this many lanes of the wave are looking
+#ifndef ZOIC_MIN_SEARCHING
+#define ZOIC_MIN_SEARCHING 16
+#endif
+constexpr uint32_t kMinSearching = ZOIC_MIN_SEARCHING;  // the candidate search goes on while at least this many lanes of the wave are looking
 
 template <bool STRICT>
 __device__ __forceinline__ V2 lens_sample(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v)

@@ -19,4 +19,17 @@ int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const flo
     return launch_kolb_pool_impl<false, false>(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
 }
 
+#ifdef ZOIC_PASS_STATS
+int read_pass_stats_dead(unsigned long long *acc8, int reset);
+#endif
+
 }  // namespace zoic
+
+#ifdef ZOIC_PASS_STATS
+extern "C" int zoic_debug_pass_stats(unsigned long long *out8, int reset)
+{
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    const int e = zoic::read_pass_stats(out8, reset);
+    return e ? e : zoic::read_pass_stats_dead(out8, reset);
+}
+#endif

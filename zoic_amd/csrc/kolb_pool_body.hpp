@@ -174,11 +174,26 @@ __device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehT
 }
 
 
-// LDS per wave: the pool, 128 entries of three 16-byte pieces each, stored piece-major (three arrays of 128 float4: a
-// push or pop is three conflict-free ds_write_b128 / ds_read_b128), then the hand-over lists (128 ray indices each).
+// Debug build only (-DZOIC_PASS_STATS, tools/pass_stats.py): pass statistics summed over all waves.  Not part of the product build.
+#ifdef ZOIC_PASS_STATS
+static __device__ unsigned long long g_passStats[8];   // A passes, B passes, search iterations, sum looking lanes, traces, sum cand lanes, sum active lanes, finished
+#define ZOIC_PS_DECL unsigned long long ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ZOIC_PS_ADD(I, V) ps[I] += (V);
+#define ZOIC_PS_FLUSH if (lane == 0) { for (int r = 0; r < 8; ++r) atomicAdd(&g_passStats[r], ps[r]); }
+#else
+#define ZOIC_PS_DECL
+#define ZOIC_PS_ADD(I, V)
+#define ZOIC_PS_FLUSH
+#endif
+
+// LDS per wave: the pool, 128 entries stored piece-major (arrays of 128 x 16 / 16 / 8 bytes: a push or pop is two
+// ds_write_b128 / ds_read_b128 and one b64, conflict-free), then the hand-over lists (128 ray indices each).
 // 128 entries: a pass starts with at most 63 pooled rays left behind and pushes at most 64.
+#ifndef ZOIC_POOL_SLIM
+#define ZOIC_POOL_SLIM 0   // 1: 40-byte entries: the exit-pupil scale / translation are looked up again when a ray is popped
+#endif
 constexpr uint32_t kPoolEntries = 128;
-constexpr uint32_t kPoolWaveWords = kPoolEntries * 12u;
+constexpr uint32_t kPoolWaveWords = kPoolEntries * (ZOIC_POOL_SLIM ? 10u : 12u);
 constexpr uint32_t kPoolListWords = 128;
 // packed word of a pooled ray: bit 0 outside the LUT, bits 1-6 the ray's TIR tally (DEFER kernels), bits 8-12 tries,
 // bit 13 dead pixel, bit 14 retry-dead
@@ -238,8 +253,12 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
     float4 *pool0 = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords + wave * kPoolWaveWords);   // idx, o0x, o0y, packed
-    float4 *pool1 = pool0 + kPoolEntries;                                                                       // maxScale, translation, sn, cs
-    uint4 *pool2 = reinterpret_cast<uint4 *>(pool1 + kPoolEntries);                                             // the ray's retry stream
+    uint4 *pool2 = reinterpret_cast<uint4 *>(pool0 + kPoolEntries);                                             // the ray's retry stream
+#if ZOIC_POOL_SLIM
+    float2 *pool1 = reinterpret_cast<float2 *>(pool2 + kPoolEntries);                                           // sn, cs
+#else
+    float4 *pool1 = reinterpret_cast<float4 *>(pool2 + kPoolEntries);                                           // maxScale, translation, sn, cs
+#endif
     uint32_t *lists = reinterpret_cast<uint32_t *>(zoicDynLds + kLutLdsWords + ldsWords + kWavesPerBlock * kPoolWaveWords) +
                       wave * ((GUARD ? kPoolListWords : 0u) + (DEAD ? kPoolListWords : 0u));
     uint32_t *unsureLds = lists;                                  // GUARD: rays for the STRICT kernel
@@ -288,10 +307,12 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     // and letting the waves that are in their memory phases issue first gets those loads out earlier; without it the launch is
     // compute-dense and the waves inside the trace go first.
     constexpr bool memoryPhasesFirst = IMAGE;
+    ZOIC_PS_DECL
     for (;;) {
         const bool drain = !have1;                                          // no fresh sample left for this wave
         const bool fromPool = poolCnt >= 64u || (drain && poolCnt != 0u);
         if (!fromPool && drain) break;
+        ZOIC_PS_ADD(fromPool ? 1 : 0, 1)
         if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(1);
         FastSurfaceTable fsurf = nullptr;
         if constexpr (GUARD && (ZOIC_GUARD_PIN != 0)) fsurf = launder_table(kernarg_fast_surfaces());   // keeps the table's s_loads at their use (fast_optics.hpp)
@@ -361,11 +382,24 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             poolCnt -= cnt;
             active = lane < cnt;
             const uint32_t slot = poolCnt + (active ? lane : 0u);
-            const float4 e0 = pool0[slot], e1 = pool1[slot];
+            const float4 e0 = pool0[slot];
             const uint4 e2 = pool2[slot];
             const uint32_t packed = __builtin_bit_cast(uint32_t, e0.w);
             idx = __builtin_bit_cast(uint32_t, e0.x); o0x = e0.y; o0y = e0.z;
+#if ZOIC_POOL_SLIM
+            const float2 e1 = pool1[slot];
+            sn = e1.x; cs = e1.y;
+            maxScale = 0.0f; translation = 0.0f;
+            if (T.useLUT) {   // the same lookup as setup_ray's, on the same operands: the same two values
+                float dist;
+                if constexpr (STRICT) dist = fabsf(ZOIC_SQRT_RN(o0x * o0x + o0y * o0y));
+                else dist = fsqrt_fast(o0x * o0x + o0y * o0y);
+                (void)lut_lookup_lds(lutLds, T.lutSize, dist, maxScale, translation);
+            }
+#else
+            const float4 e1 = pool1[slot];
             maxScale = e1.x; translation = e1.y; sn = e1.z; cs = e1.w;
+#endif
             rng = Rng{e2.x, e2.y, e2.z, e2.w};
             tries = (packed >> kPoolTriesShift) & 31u;
             dead = (packed & kPoolDeadBit) != 0u;
@@ -383,6 +417,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         for (;;) {
             const uint32_t looking = static_cast<uint32_t>(__popcll(__ballot(searching)));
             if (looking < (drain ? 1u : minSearching)) break;
+            ZOIC_PS_ADD(2, 1) ZOIC_PS_ADD(3, looking)
             if (searching) {
                 if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
                     const uint4 *states = ZOIC_KARG(rngStates);
@@ -409,7 +444,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         const V3 oStart = o, dStart = d;
         const bool firstTry = tries == 0;
         const unsigned long long candMask = __ballot(cand);
+        ZOIC_PS_ADD(6, __popcll(__ballot(active)))
         if (candMask != 0ull) {
+            ZOIC_PS_ADD(4, 1) ZOIC_PS_ADD(5, __popcll(candMask))
             if (memoryPhasesFirst) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
             uint32_t tirTry = 0;   // 0/1: this try ended in total internal reflection
             if constexpr (NS > 0) {
@@ -469,6 +506,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             const uint32_t nv = static_cast<uint32_t>(__popcll(__ballot(finished && tries > static_cast<uint32_t>(kMaxTries))));
             vign += nv;                                                                       // zoic.cpp:1951-1957
             succ += static_cast<uint32_t>(__popcll(__ballot(finished))) - nv;
+            ZOIC_PS_ADD(7, __popcll(__ballot(finished)))
         }
         if (finished) {
             float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;
@@ -499,7 +537,11 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                     const uint32_t packed = (lutMiss & 0x7fu) | (tries << kPoolTriesShift) | (dead ? kPoolDeadBit : 0u) |
                                             ((lutMiss & kRetryDeadBit) ? kPoolRetryDeadBit : 0u);
                     pool0[slot] = make_float4(__builtin_bit_cast(float, idx), o0x, o0y, __builtin_bit_cast(float, packed));
+#if ZOIC_POOL_SLIM
+                    pool1[slot] = make_float2(sn, cs);
+#else
                     pool1[slot] = make_float4(maxScale, translation, sn, cs);
+#endif
                     pool2[slot] = make_uint4(rng.x, rng.y, rng.z, rng.w);
                 }
                 poolCnt += static_cast<uint32_t>(__popcll(m));
@@ -550,6 +592,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
         tir += static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
     }
+    ZOIC_PS_FLUSH
     // ---- counters: the wave totals, one atomic per counter per wave -------------------------------------------------------
     DeviceCounters *counters = counter_set(ZOIC_KARG(counters));
     if (counters) {
@@ -634,6 +677,18 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
     }
     return 0;
 }
+
+#ifdef ZOIC_PASS_STATS
+static int read_pass_stats(unsigned long long *acc8, int reset)   // adds this translation unit's copy
+{
+    unsigned long long v[8];
+    hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_passStats), sizeof(v));
+    if (e != hipSuccess) return static_cast<int>(e);
+    for (int i = 0; i < 8; ++i) acc8[i] += v[i];
+    if (reset) { const unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_passStats), z, sizeof(z)); }
+    return static_cast<int>(e);
+}
+#endif
 
 // cell records usable by the IMAGE kernels: present and small enough for LDS (tables.hpp)
 inline bool kolb_image_cells(const KolbTable &table, const BokehTables &bokeh)

@@ -14,4 +14,8 @@ int launch_kolb_pool_dead(const KolbTable &table, const BokehTables &bokeh, cons
     return launch_kolb_pool_impl<true, false>(table, bokeh, d_samples, d_rng, rayBase, n, out, d_counters, d_workCursor, mode, d_scratch, stream);
 }
 
+#ifdef ZOIC_PASS_STATS
+int read_pass_stats_dead(unsigned long long *acc8, int reset) { return read_pass_stats(acc8, reset); }
+#endif
+
 }  // namespace zoic

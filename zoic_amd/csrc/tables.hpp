@@ -118,10 +118,11 @@ struct BokehTables {
     // Cell records (y <= 2048, x <= 4096; built when both CDFs are non-decreasing): the unit interval of the sample is
     // cut into G = 2^k >= n cells; for cell g = floor(u*G) (exact: G is a power of two) the record holds everything
     // std::upper_bound needs when at most two CDF entries fall inside the cell:
-    //   .x = cdf[lo] as bits, .y = cdf[lo+1] as bits (+inf past the end)       lo = #{cdf <= g/G}
-    //   .z = idx[lo] | idx[lo+1] << 16                                           idx = pixel index (clamped to n-1)
-    //   .w = idx[lo+2] | exceptional << 31                                       exceptional: #{g/G < cdf < (g+1)/G} > 2
-    // so upper_bound(u) = lo + (cdf[lo] <= u) + (cdf[lo+1] <= u) and the pixel index comes out of the same 16 bytes.
+    //   .x = a as bits, .y = b as bits: the first two DISTINCT CDF values above g/G (+inf past the end); lo = #{cdf <= g/G},
+    //        j = first entry > a, k = first entry > b  (a run of equal values -- the zero-luminance tail -- is one decision)
+    //   .z = idx[lo] | idx[j] << 16                                              idx = pixel index (clamped to n-1)
+    //   .w = idx[k] | exceptional << 31                                          exceptional: a third distinct value < (g+1)/G
+    // so indices[min(upper_bound(u), n-1)] = u < a ? idx[lo] : u < b ? idx[j] : idx[k], out of the same 16 bytes.
     // Exceptional cells finish with std::upper_bound over [lo, hi) of the reference arrays; their bounds
     // (lo | hi << 16, hi = #{cdf < (g+1)/G}) sit in side tables only that path reads.
     // The row record table (rowCells) is copied to LDS once per workgroup: a lens sample is ONE ds_read_b128 plus ONE
