@@ -152,9 +152,12 @@ zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d
 /* same, host buffers: H2D, kernels, D2H in pieces on two private streams; returns when h_rays is complete */
 zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_samples, const uint32_t *h_rng_states,
                                   uint64_t ray_index_base, zoic_ray *h_rays);
-/* Arnold-layout batch: n AtCameraInput -> n AtCameraOutput (host).  outputs must arrive initialised the way
- * Arnold hands them to camera_create_ray (origin 0, weight 1; thin-lens reads output.origin, zoic.cpp:1777).
- * Ray i draws its retries from the stream keyed by ray_index_base + i (see zoic_create_rays_device). */
+/* Arnold-layout batch: n AtCameraInput -> n AtCameraOutput (host arrays; page-locked ones -- zoic_host_alloc /
+ * zoic_host_register -- move at PCIe rate).  Every output row is WRITTEN WHOLE (the expansion runs on the GPU): origin, dir,
+ * weight[3] = the exposure factor or 0 (the caller's initial weight is taken as 1), dOdy = origin and dDdy = dir for rays
+ * that retried (zoic.cpp:1974-1977), and 0 in what camera_create_ray leaves alone (dOdx, dDdx; dOdy, dDdy of first-try
+ * rays) -- the values of a zero-initialised AtCameraOutput.  The thin-lens branch reads output.origin (zoic.cpp:1777): it is
+ * taken as 0, as Arnold hands it in.  Ray i draws its retries from the stream keyed by ray_index_base + i. */
 zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_camera_input *inputs,
                                     zoic_camera_output *outputs, uint64_t ray_index_base);
 /* camera_create_ray(node, input, output, tid), zoic.cpp:1752: the per-sample signature (latency bound: one launch

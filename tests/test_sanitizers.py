@@ -8,26 +8,7 @@ import subprocess
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "tests", "native", "build")
-SAN = {"tsan": ["-fsanitize=thread"], "asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]}
-
-
-def _build(kind):
-    from zoic_amd import build as zbuild
-    os.makedirs(OUT, exist_ok=True)
-    lib = os.path.join(OUT, "libzoic_amd_%s.so" % kind)
-    flags = SAN[kind] + ["-g", "-O1"]
-    srcs = [os.path.join(zbuild.CSRC, s) for s in zbuild.SOURCES] + [os.path.join(zbuild.CSRC, h) for h in zbuild.HEADERS if not os.path.isabs(h)]
-    drv_src = os.path.join(ROOT, "tests", "native", "boundary_stress.cpp")
-    exe = os.path.join(OUT, "boundary_stress_%s" % kind)
-    newest = max(os.path.getmtime(p) for p in srcs + [drv_src, os.path.join(ROOT, "include", "zoic_amd.h")])
-    if not (os.path.exists(lib) and os.path.exists(exe) and min(os.path.getmtime(lib), os.path.getmtime(exe)) > newest):
-        zbuild.build(force=False, extra_flags=flags, out=lib, objdir=os.path.join(OUT, "obj_" + kind))
-        cxx = "/opt/rocm/lib/llvm/bin/clang++"   # the compiler hipcc drives: same sanitizer runtime as the library
-        subprocess.check_call([cxx, "-std=c++17", "-O1", "-g"] + SAN[kind] + ["-I" + os.path.join(ROOT, "include"), drv_src,
-                               "-o", exe, "-L" + OUT, "-l:" + os.path.basename(lib), "-Wl,-rpath," + OUT, "-lpthread"])
-    return exe
+from native_build import OUT, ROOT, build as _build
 
 
 def _run(exe, args, kind):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzoic_amd.so")
-SOURCES = ["capi.cpp", "lens_system.cpp", "kernels.hip", "kolb_pool.hip", "kolb_pool_dead.hip", "thin_refill.hip", "bokeh_cdf.hip"]
+SOURCES = ["capi.cpp", "lens_system.cpp", "kernels.hip", "kolb_pool.hip", "kolb_pool_dead.hip", "thin_refill.hip", "bokeh_cdf.hip", "mailbox.hip"]
 # every header of csrc/ is a dependency of every object (a hand-kept list went stale twice: exact_math.hpp, kolb_refill_body.hpp)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(ROOT, "include", "zoic_amd.h")]
 
@@ -52,10 +52,18 @@ def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
     extra_flags = list(extra_flags) + os.environ.get("ZOIC_EXTRA_HIPCC_FLAGS", "").split()
     if out == LIB and not extra_flags and not force and not needs_build():
         return LIB
-    objdir = objdir or (OBJDIR if not extra_flags else OBJDIR + "_" + "%08x" % (hash(" ".join(extra_flags)) & 0xffffffff))
+    import zlib
+    objdir = objdir or (OBJDIR if not extra_flags else OBJDIR + "_" + "%08x" % zlib.crc32(" ".join(extra_flags).encode()))
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     cflags = [f for f in FLAGS if f != "-shared"] + extra_flags
+    # objects are only reused under the flags they were compiled with (the stamp also catches an edited FLAGS list)
+    stamp = os.path.join(objdir, "flags.stamp")
+    flagline = " ".join(cflags)
+    if not os.path.exists(stamp) or open(stamp).read() != flagline:
+        force = True
+        with open(stamp, "w") as f:
+            f.write(flagline)
     newest_header = max(os.path.getmtime(d) for d in _deps())
     procs, objs = [], []
     for src in SOURCES:

@@ -29,6 +29,7 @@
 
 #include "../../include/zoic_amd.h"
 #include "kernels.hpp"
+#include "mailbox.hpp"
 #include "lens_system.hpp"
 
 #pragma STDC FP_CONTRACT OFF
@@ -139,8 +140,7 @@ struct CallContext {
     DeviceBuffer<float> dSamples[2], dInputs7[2];
     DeviceBuffer<RayRecord> dRays[2];
     DeviceBuffer<uint32_t> dRng[2];
-    PinnedBuffer hRays[2];                       // Arnold-layout path: records land here, the host expands them to 84 bytes
-    PinnedBuffer one;                            // per-sample adapter: {sample 16 B, rng state 16 B, ray record 32 B}, zero-copy
+    DeviceBuffer<float> dOut21[2];               // Arnold-layout path: the records expanded to AtCameraOutput rows (21 floats)
     hipError_t init()
     {
         hipError_t e = hipStreamCreateWithFlags(&sIn, hipStreamNonBlocking);
@@ -151,8 +151,7 @@ struct CallContext {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&runDone[b], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&outDone[b], hipEventDisableTiming);
         }
-        if (e != hipSuccess) return e;
-        return one.reserve(64);
+        return e;
     }
     hipError_t sync_all()
     {
@@ -169,9 +168,53 @@ struct CallContext {
         for (hipStream_t *st : {&sIn, &sRun, &sOut}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
         for (int b = 0; b < 2; ++b) {
             for (hipEvent_t *ev : {&inDone[b], &runDone[b], &outDone[b]}) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
-            dSamples[b].release(); dInputs7[b].release(); dRays[b].release(); dRng[b].release(); hRays[b].release();
+            dSamples[b].release(); dInputs7[b].release(); dRays[b].release(); dRng[b].release(); dOut21[b].release();
         }
-        one.release();
+    }
+};
+
+// The per-sample mailbox (mailbox.hip): header + 64 requests + 64 replies in ONE mapped, page-locked allocation, the
+// sequence numbers the resident kernel has answered in device memory (they survive its retirements), a private stream.
+struct Mailbox {
+    std::mutex launchM;                        // launch / stop of the resident kernel
+    PinnedBuffer mem;
+    uint32_t *dServed = nullptr;
+    hipStream_t stream = nullptr;
+    std::mutex slotM[kMailSlots];              // one call per slot at a time (tids 64 apart share a slot)
+    uint32_t seq[kMailSlots] = {};
+    std::atomic<uint32_t> slotsInUse{0};       // slots the resident launch watches; written under launchM (0: not initialised)
+    volatile MailHeader *header() const { return static_cast<volatile MailHeader *>(mem.host); }
+    volatile MailRequest *request(unsigned slot) const { return reinterpret_cast<volatile MailRequest *>(static_cast<char *>(mem.host) + 64) + slot; }
+    volatile MailReply *reply(unsigned slot) const { return reinterpret_cast<volatile MailReply *>(static_cast<char *>(mem.host) + 64 + 64 * kMailSlots) + slot; }
+    hipError_t init()
+    {
+        if (mem.host) return hipSuccess;
+        hipError_t e = mem.reserve(64 + 2 * 64 * kMailSlots);
+        if (e != hipSuccess) return e;
+        std::memset(mem.host, 0, mem.cap);
+        e = hipMalloc(reinterpret_cast<void **>(&dServed), (kMailSlots + 4) * sizeof(uint32_t));   // + the launch's control block
+        if (e == hipSuccess) e = hipMemset(dServed, 0, (kMailSlots + 4) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        return e;
+    }
+    // the resident kernel retires (adding its ray counters to the camera's) and nothing of it is left in flight
+    hipError_t stop()
+    {
+        std::lock_guard<std::mutex> lk(launchM);
+        if (!mem.host || !stream) return hipSuccess;
+        request(0)->stop = 1u;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        const hipError_t e = hipStreamSynchronize(stream);
+        request(0)->stop = 0u;
+        header()->alive = 0u;
+        return e;
+    }
+    void release()
+    {
+        (void)stop();
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (dServed) { (void)hipFree(dServed); dServed = nullptr; }
+        mem.release();
     }
 };
 
@@ -218,6 +261,7 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     std::mutex poolM;
     std::vector<CallContext *> freeContexts;
     std::vector<std::unique_ptr<CallContext>> contexts;
+    Mailbox mail;                           // camera_create_ray per sample (mailbox.hip)
     std::unique_ptr<std::atomic<TidState *>[]> tidStates;   // kTidStates entries, created on first use
     std::mutex tidCreateM;
 
@@ -663,6 +707,7 @@ void zoic_camera_destroy(zoic_camera *cam)
     if (cam->device == ZOIC_DEVICE_NONE) { delete cam; return; }
     {
         DeviceGuard guard(cam->device);
+        cam->mail.release();
         (void)hipDeviceSynchronize();   // launches the caller left in flight still read the tables and cursors freed below
         for (auto &c : cam->contexts) c->release();
         cam->contexts.clear(); cam->freeContexts.clear();
@@ -706,6 +751,11 @@ zoic_status zoic_camera_set_precision(zoic_camera *cam, zoic_precision mode)
 {
     if (!cam || (mode != ZOIC_PRECISION_STRICT && mode != ZOIC_PRECISION_FAST && mode != ZOIC_PRECISION_FAST_UNCHECKED))
         return fail(ZOIC_ERR_INVALID_ARGUMENT, "bad precision");
+    if (cam->device != ZOIC_DEVICE_NONE && mode != cam->precision) {   // the resident per-sample kernel is launched for ONE mode
+        DeviceGuard guard(cam->device);
+        ZOIC_HIP(guard.error());
+        ZOIC_HIP(cam->mail.stop());
+    }
     cam->precision = mode;
     return ZOIC_OK;
 }
@@ -737,7 +787,8 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
         guard.reset(new DeviceGuard(cam->device));
         ZOIC_HIP(guard->error());
         // node_update never runs beside camera_create_ray (Arnold's contract), but launches the caller queued earlier
-        // may still be reading the tables rebuilt below
+        // may still be reading the tables rebuilt below; the resident per-sample kernel holds the old tables by value
+        ZOIC_HIP(cam->mail.stop());
         ZOIC_HIP(hipDeviceSynchronize());
     }
     const std::string bokehPath = p->bokehPath ? p->bokehPath : "", lensPath = p->lensDataPath ? p->lensDataPath : "";
@@ -923,54 +974,82 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
     ContextLease lease(cam);
     if (!lease) return fail(ZOIC_ERR_HIP, std::string("call context: ") + hipGetErrorString(lease.error()));
     CallContext &C = *lease;
-    // Same three-stream pipeline as zoic_create_rays_host; the 32-byte records land in the context's pinned buffers and the
-    // host expands piece k into AtCameraOutput layout while pieces k+1, k+2 are on the GPU / on the wire.
+    // Same three-stream pipeline as zoic_create_rays_host.  The 32-byte records are expanded to AtCameraOutput rows ON THE
+    // GPU (kernels.hip expand_outputs_kernel) and leave as whole 84-byte rows straight into the caller's array: the host
+    // touches nothing (round 2 expanded on the calling thread: 84 Mrays/s per thread against PCIe's ~0.45 Grays/s).
     const uint64_t piece = host_piece(n);
     const size_t cap = static_cast<size_t>(std::min<uint64_t>(n, piece));
     for (int b = 0; b < 2 && (b == 0 || n > piece); ++b) {
         ZOIC_HIP(C.dInputs7[b].reserve(cap * 7));
         ZOIC_HIP(C.dSamples[b].reserve(cap * 4));
         ZOIC_HIP(C.dRays[b].reserve(cap));
-        ZOIC_HIP(C.hRays[b].reserve(cap * sizeof(zoic_ray)));
+        ZOIC_HIP(C.dOut21[b].reserve(cap * 21));
     }
     zoic_status status = ZOIC_OK;
-    uint64_t k = 0, prevOff = 0, prevM = 0;
-    int prevB = -1;
-    const auto expand_piece = [&](int b, uint64_t off, uint64_t m) -> hipError_t {
-        const hipError_t e = hipEventSynchronize(C.outDone[b]);
-        if (e != hipSuccess) return e;
-        const zoic_ray *r = static_cast<const zoic_ray *>(C.hRays[b].host);
-        for (uint64_t i = 0; i < m; ++i) expand_record(r[i], outputs[off + i]);
-        return hipSuccess;
-    };
+    uint64_t k = 0;
     for (uint64_t off = 0; off < n && status == ZOIC_OK; off += piece, ++k) {
         const int b = static_cast<int>(k & 1u);
         const uint64_t m = std::min<uint64_t>(piece, n - off);
         hipError_t e = hipSuccess;
-        // hRays[b] is read by the host's expansion of piece k-2, which ran (below) before this iteration: free.
-        if (k >= 2) e = hipStreamWaitEvent(C.sIn, C.runDone[b], 0);
+        if (k >= 2) e = hipStreamWaitEvent(C.sIn, C.runDone[b], 0);   // dInputs7[b] is free once piece k-2's kernels are done
         if (e == hipSuccess) e = hipMemcpyAsync(C.dInputs7[b].ptr, inputs + off, m * sizeof(zoic_camera_input), hipMemcpyHostToDevice, C.sIn);
         if (e == hipSuccess) e = hipEventRecord(C.inDone[b], C.sIn);
         if (e == hipSuccess) e = hipStreamWaitEvent(C.sRun, C.inDone[b], 0);
-        if (e == hipSuccess && k >= 2) e = hipStreamWaitEvent(C.sRun, C.outDone[b], 0);
+        if (e == hipSuccess && k >= 2) e = hipStreamWaitEvent(C.sRun, C.outDone[b], 0);   // dOut21[b] back from piece k-2's copy-out
         if (e == hipSuccess) e = static_cast<hipError_t>(launch_pack_inputs(C.dInputs7[b].ptr, C.dSamples[b].ptr, m, C.sRun));
         if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("H2D + pack: ") + hipGetErrorString(e)); break; }
         status = launch_rays(cam, m, C.dSamples[b].ptr, nullptr, ray_index_base + off, C.dRays[b].ptr, C.sRun);
         if (status != ZOIC_OK) break;
-        e = hipEventRecord(C.runDone[b], C.sRun);
+        e = static_cast<hipError_t>(launch_expand_outputs(C.dRays[b].ptr, C.dOut21[b].ptr, m, C.sRun));
+        if (e == hipSuccess) e = hipEventRecord(C.runDone[b], C.sRun);
         if (e == hipSuccess) e = hipStreamWaitEvent(C.sOut, C.runDone[b], 0);
-        if (e == hipSuccess) e = hipMemcpyAsync(C.hRays[b].host, C.dRays[b].ptr, m * sizeof(zoic_ray), hipMemcpyDeviceToHost, C.sOut);
+        if (e == hipSuccess) e = hipMemcpyAsync(outputs + off, C.dOut21[b].ptr, m * sizeof(zoic_camera_output), hipMemcpyDeviceToHost, C.sOut);
         if (e == hipSuccess) e = hipEventRecord(C.outDone[b], C.sOut);
-        if (e == hipSuccess && prevB >= 0) e = expand_piece(prevB, prevOff, prevM);   // overlaps this piece's GPU work
-        if (e != hipSuccess) { status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e)); break; }
-        prevB = b; prevOff = off; prevM = m;
+        if (e != hipSuccess) status = fail(ZOIC_ERR_HIP, std::string("expand + D2H: ") + hipGetErrorString(e));
     }
-    if (status == ZOIC_OK && prevB >= 0) {
-        const hipError_t e = expand_piece(prevB, prevOff, prevM);
-        if (e != hipSuccess) status = fail(ZOIC_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+    {   // own streams only: other threads' calls are not waited for
+        const hipError_t e = C.sync_all();
+        if (e != hipSuccess && status == ZOIC_OK) status = fail(ZOIC_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(e));
     }
-    if (status != ZOIC_OK) (void)C.sync_all();   // nothing of ours left in flight
     return status;
+}
+
+// the resident per-sample kernel is running (or has just been started); see mailbox.hip
+static zoic_status mailbox_ensure_running(zoic_camera *cam, unsigned slot)
+{
+    Mailbox &M = cam->mail;
+    std::lock_guard<std::mutex> lk(M.launchM);
+    ZOIC_HIP(M.init());
+    volatile MailHeader *h = M.header();
+    if (slot + 1 > M.slotsInUse.load(std::memory_order_relaxed)) {
+        // a tid beyond the slots the resident launch watches: it retires (stop flag) and starts again watching more
+        if (h->alive != 0u) {
+            M.request(0)->stop = 1u;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            ZOIC_HIP(hipStreamSynchronize(M.stream));
+            M.request(0)->stop = 0u; h->alive = 0u;
+        }
+        h->slotsInUse = slot + 1;
+        M.slotsInUse.store(slot + 1, std::memory_order_release);
+    }
+    if (h->alive != 0u) {
+        // alive is cleared by the kernel's last store; a kernel that died without it leaves the stream idle (or in error)
+        const hipError_t q = hipStreamQuery(M.stream);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return ZOIC_OK; }
+        if (q != hipSuccess) return fail(ZOIC_ERR_HIP, std::string("per-sample kernel: ") + hipGetErrorString(q));
+    }
+    ZOIC_HIP(hipStreamSynchronize(M.stream));   // the previous resident kernel has retired (its last store is long done)
+    const int model = cam->params.p.lensModel;
+    const int mode = cam->precision == ZOIC_PRECISION_STRICT ? 0 : (cam->precision == ZOIC_PRECISION_FAST ? 1 : 2);
+    M.request(0)->stop = 0u;
+    h->alive = 1u;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    char *d = static_cast<char *>(M.mem.dev);
+    const int rc = launch_mailbox(cam->kolb, cam->thin, cam->bokehDev, model, mode, reinterpret_cast<MailHeader *>(d),
+                                  reinterpret_cast<const MailRequest *>(d + 64), reinterpret_cast<MailReply *>(d + 64 + 64 * kMailSlots), M.dServed,
+                                  M.dServed + kMailSlots, cam->dCounters, M.stream);
+    if (rc != 0) { h->alive = 0u; return fail(ZOIC_ERR_HIP, std::string("per-sample kernel launch: ") + hipGetErrorString(static_cast<hipError_t>(rc))); }
+    return ZOIC_OK;
 }
 
 zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output, uint16_t tid)
@@ -979,27 +1058,43 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
     // race on one global xor128 state; here each tid owns a retry stream that carries over from call to call, and tid 0's
     // stream is the camera's own reference state (the one node_update's LUT build draws from), so a single-threaded
     // sequence of update / create_ray calls reproduces the reference process draw for draw.
+    // No launch per call: the sample goes to the resident mailbox kernel (mailbox.hip) through mapped pinned memory.
     if (zoic_status s = check_ray_call(cam)) return s;
     if (!input || !output) return fail(ZOIC_ERR_INVALID_ARGUMENT, "NULL argument");
+    const int model = cam->params.p.lensModel;
+    if (model != ZOIC_RAYTRACED && model != ZOIC_THINLENS)
+        return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
     DeviceGuard guard(cam->device);
     ZOIC_HIP(guard.error());
     TidState *T = cam->tid_state(tid);
     std::lock_guard<std::mutex> tidLock(T->m);
     Rng &rng = tid == 0 ? cam->stream : T->rng;
-    ContextLease lease(cam);
-    if (!lease) return fail(ZOIC_ERR_HIP, std::string("call context: ") + hipGetErrorString(lease.error()));
-    CallContext &C = *lease;
-    // zero-copy: the kernel reads the sample and the stream state from, and writes the record to, mapped pinned memory
-    struct Block { float sample[4]; uint32_t rng[4]; zoic_ray ray; };
-    static_assert(sizeof(Block) == 64, "per-sample block");
-    Block *h = static_cast<Block *>(C.one.host);
-    Block *d = static_cast<Block *>(C.one.dev);
-    h->sample[0] = input->sx; h->sample[1] = input->sy; h->sample[2] = input->lensx; h->sample[3] = input->lensy;
-    h->rng[0] = rng.x; h->rng[1] = rng.y; h->rng[2] = rng.z; h->rng[3] = rng.w;
-    if (zoic_status s = launch_rays(cam, 1, d->sample, d->rng, 0, reinterpret_cast<RayRecord *>(&d->ray), C.sRun)) return s;
-    ZOIC_HIP(hipStreamSynchronize(C.sRun));
-    const zoic_ray r = h->ray;
-    // every retry drew two numbers (zoic.cpp:1806 / 1881 / 1930), whether or not the kernel short-cut them
+    Mailbox &M = cam->mail;
+    const unsigned slot = tid % kMailSlots;
+    std::lock_guard<std::mutex> slotLock(M.slotM[slot]);
+    if (M.slotsInUse.load(std::memory_order_acquire) <= slot || M.header()->alive == 0u)
+        if (zoic_status s = mailbox_ensure_running(cam, slot)) return s;
+    // request: data words first, the sequence number last in every 16-byte chunk (x86 stores stay in program order)
+    const uint32_t seq = ++M.seq[slot];
+    volatile MailRequest *q = M.request(slot);
+    q->rngZ = rng.z; q->rngW = rng.w; q->pad2 = 0u;
+    q->lensy = input->lensy; q->rngX = rng.x; q->rngY = rng.y;
+    q->sx = input->sx; q->sy = input->sy; q->lensx = input->lensx;
+    std::atomic_thread_fence(std::memory_order_release);
+    q->seq2 = seq; q->seq1 = seq; q->seq0 = seq;
+    // reply: complete when its three chunks carry this call's number
+    volatile MailReply *a = M.reply(slot);
+    for (uint32_t spins = 1;; ++spins) {
+        if (a->seq0 == seq && a->seq1 == seq && a->seq2 == seq) break;
+        __builtin_ia32_pause();
+        if ((spins & 2047u) == 0u && M.header()->alive == 0u) {   // the kernel retired (idle / lifetime) around this call: start it again
+            if (zoic_status s = mailbox_ensure_running(cam, slot)) return s;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    zoic_ray r;
+    r.ox = a->ox; r.oy = a->oy; r.oz = a->oz; r.dx = a->dx; r.dy = a->dy; r.dz = a->dz; r.weight = a->weight; r.flags = a->flags;
+    // every retry drew two numbers (zoic.cpp:1806 / 1881 / 1930)
     const uint32_t tries = (r.flags >> 1) & 31u;
     for (uint32_t i = 0; i < 2u * tries; ++i) (void)xor128(rng);
     expand_record(r, *output);
@@ -1060,6 +1155,7 @@ zoic_status zoic_camera_get_counters(zoic_camera *cam, zoic_counters *out)
     }
     DeviceGuard guard(cam->device);
     ZOIC_HIP(guard.error());
+    ZOIC_HIP(cam->mail.stop());         // the resident per-sample kernel adds its counts when it retires
     ZOIC_HIP(hipDeviceSynchronize());   // every stream of the device: launches of all threads are counted
     std::vector<DeviceCounters> sets(kCounterSets);
     ZOIC_HIP(hipMemcpy(sets.data(), cam->dCounters, kCounterSets * sizeof(DeviceCounters), hipMemcpyDeviceToHost));
@@ -1075,6 +1171,7 @@ zoic_status zoic_camera_reset_counters(zoic_camera *cam)
     if (cam->device == ZOIC_DEVICE_NONE) return ZOIC_OK;
     DeviceGuard guard(cam->device);
     ZOIC_HIP(guard.error());
+    ZOIC_HIP(cam->mail.stop());
     ZOIC_HIP(hipDeviceSynchronize());
     ZOIC_HIP(hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters)));
     return ZOIC_OK;

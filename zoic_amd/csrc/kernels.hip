@@ -17,6 +17,7 @@
 #include "kernels.hpp"
 #include "ray_store.hpp"
 #include "optics.hpp"
+#include "thin_device.hpp"
 
 #pragma STDC FP_CONTRACT OFF
 
@@ -46,34 +47,16 @@ __device__ __forceinline__ void flush_counters(DeviceCounters *c, uint32_t succ,
     }
 }
 
-// rowCellsLds: the workgroup's LDS copy of the bokeh row cell records (nullptr: pyramid / reference search)
-__device__ __forceinline__ V2 sample_lens(bool useImage, const BokehTables &B, const float *rowCellsLds, int bw, int bh, float u, float v)
-{
-    if (useImage) {
-        if (rowCellsLds) return bokeh_sample_cells<true>(B, rowCellsLds, bw, bh, u, v);
-        return bokeh_sample_device(B, bw, bh, u, v);
-    }
-    return concentric_disk(u, v);
-}
-
 extern __shared__ __align__(16) float thinDynLds[];   // bokeh row cell records (thin-lens kernel), after the static LDS
 
 // ------------------------------------------------------------------------------------- THINLENS
-// zoic.cpp:1771-1846 + empericalOpticalVignetting zoic.cpp:1297-1305.  All f32; ~60 flop / 44 B: HBM-bound.
-__device__ __forceinline__ bool optical_vignet_pass(const ThinTable &T, V3 origin, V3 dir)
-{
-    const V3 p{dir.x * T.ovDistance - origin.x, dir.y * T.ovDistance - origin.y, dir.z * T.ovDistance - origin.z};
-    const float hyp = sqrtf((p.x * p.x) + (p.y * p.y));
-    return fabsf(hyp) < T.apertureRadius * T.ovRadius;
-}
-
+// zoic.cpp:1771-1846 + empericalOpticalVignetting zoic.cpp:1297-1305 (thin_device.hpp).  All f32; ~60 flop / 44 B: HBM-bound.
 __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, const BokehTables B,
                                                            const float4 *__restrict__ samples,
                                                            const uint4 *__restrict__ rngStates, uint64_t rayBase, uint64_t n,
                                                            RayRecord *__restrict__ out, DeviceCounters *counters, uint32_t ldsWords)
 {
     uint32_t succ = 0, vign = 0;
-    const bool useImage = T.useImage != 0;
     __shared__ float4 stage[kBlock / 64][128];   // per-wave transpose buffer for the coalesced record store
     const float *rowCells = nullptr;
     if (ldsWords > 0) {                          // bokeh row cell records, once per workgroup (tables.hpp)
@@ -97,44 +80,14 @@ __global__ __launch_bounds__(kBlock) void thin_rays_kernel(const ThinTable T, co
             sNext = nt_load(samples + (j < n ? j : n - 1));
         }
         Rng rng{1u, 2u, 3u, 4u};
-        bool seeded = false;   // the private retry stream is seeded at the first retry only
-        const V3 p{s.x * T.tanFov, s.y * T.tanFov, 1.0f};
-        const V3 originOriginal{0.0f, 0.0f, 0.0f};  // Arnold hands output.origin in as 0 (zoic.cpp:1777 reads it)
-        const V3 dir0 = normalize3(V3{p.x - originOriginal.x, p.y - originOriginal.y, p.z - originOriginal.z});
-        V3 origin = originOriginal, dir = dir0;
-        int tries = 0;
-        float w = 1.0f;
-        if (T.useDof) {
-            V2 lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, s.z, s.w);
-            lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
-            origin = V3{lens.x, lens.y, 0.0f};
-            const float inter = fabsf(T.focalDistance / dir0.z);
-            const V3 fp{dir0.x * inter, dir0.y * inter, dir0.z * inter};
-            dir = normalize3(V3{fp.x - origin.x, fp.y - origin.y, fp.z - origin.z});
-            if (T.ovDistance > 0.0f) {
-                while (!optical_vignet_pass(T, origin, dir) && tries <= kMaxTries) {  // zoic.cpp:1804-1819
-                    if (!seeded) {
-                        if (rngStates) { const uint4 r = rngStates[have ? i : n - 1]; rng = Rng{r.x, r.y, r.z, r.w}; }
-                        else rng = rng_for_ray(T.seed, rayBase + i);
-                        seeded = true;
-                    }
-                    const float u = rng_unit(xor128(rng));
-                    const float v = rng_unit(xor128(rng));
-                    lens = sample_lens(useImage, B, rowCells, T.bokehW, T.bokehH, u, v);
-                    lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
-                    origin = V3{lens.x, lens.y, 0.0f};
-                    dir = normalize3(V3{fp.x - origin.x, fp.y - origin.y, fp.z - origin.z});  // dir0, inter, fp are loop invariant
-                    ++tries;
-                }
-            }
-            if (have) { if (tries > kMaxTries) { w = 0.0f; ++vign; } else ++succ; }  // zoic.cpp:1824-1830
-            else if (tries > kMaxTries) w = 0.0f;
-        }
-        dir.z = dir.z * -1.0f;                     // zoic.cpp:1845
-        if (T.exposureOn) w *= T.exposureMul;
+        const ThinRay r = thin_ray_strict(T, B, rowCells, s, rng, [&] {   // the private retry stream is seeded at the first retry only
+            if (rngStates) { const uint4 q = rngStates[have ? i : n - 1]; rng = Rng{q.x, q.y, q.z, q.w}; }
+            else rng = rng_for_ray(T.seed, rayBase + i);
+        });
+        if (T.useDof && have) { if (r.tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ; }  // zoic.cpp:1824-1830
         const uint64_t left = n - waveBase;
-        store_ray_records_wave(out, waveBase, lane, left < 64 ? static_cast<uint32_t>(left) : 64u, stage[wave], origin.x, origin.y,
-                               origin.z, dir.x, dir.y, dir.z, w, (tries > 0 ? 1u : 0u) | (static_cast<uint32_t>(tries) << 1));
+        store_ray_records_wave(out, waveBase, lane, left < 64 ? static_cast<uint32_t>(left) : 64u, stage[wave], r.origin.x, r.origin.y,
+                               r.origin.z, r.dir.x, r.dir.y, r.dir.z, r.w, (r.tries > 0 ? 1u : 0u) | (r.tries << 1));
     }
     flush_counters(counters, succ, vign, 0u);
 }
@@ -190,6 +143,27 @@ __global__ __launch_bounds__(kBlock) void pack_inputs_kernel(const float *__rest
     }
 }
 
+// 32-byte records -> AtCameraOutput rows (84 bytes = 21 floats: origin, dir, dOdx, dOdy, dDdx, dDdy, weight[3]), the fields
+// camera_create_ray writes (zoic.cpp:1960-1961 origin / dir, 1974-1977 dOdy = origin and dDdy = dir for retried rays,
+// 1952 / 1981-1987 weight) and zeros in the ones it leaves alone.  One lane per output FLOAT: stores are fully coalesced
+// (the 21 lanes of a ray read its one record through the L1).
+__global__ __launch_bounds__(kBlock) void expand_outputs_kernel(const RayRecord *__restrict__ rays, float *__restrict__ out21, uint64_t n)
+{
+    const uint64_t total = n * 21u, stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t ray = t / 21u;
+        const uint32_t f = static_cast<uint32_t>(t - ray * 21u);
+        const float *r = reinterpret_cast<const float *>(rays + ray);
+        const bool retried = (__builtin_bit_cast(uint32_t, r[7]) & 1u) != 0u;
+        float v = 0.0f;                                  // dOdx (6-8), dDdx (12-14); dOdy / dDdy of first-try rays
+        if (f < 6u) v = r[f];                            // origin, dir
+        else if (f >= 18u) v = r[6];                     // weight r = g = b (the caller's initial weight is 1)
+        else if (retried && f >= 9u && f < 12u) v = r[f - 9u];    // dOdy = origin
+        else if (retried && f >= 15u) v = r[f - 12u];             // dDdy = dir
+        out21[t] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline unsigned grid_for(uint64_t n)
 {
@@ -238,6 +212,13 @@ int launch_pack_inputs(const float *d_inputs7, float *d_samples4, uint64_t n, vo
     if (n == 0) return 0;
     hipLaunchKernelGGL(pack_inputs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_inputs7,
                        reinterpret_cast<float4 *>(d_samples4), n);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_expand_outputs(const RayRecord *d_rays, float *d_out21, uint64_t n, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(expand_outputs_kernel, dim3(grid_for(n * 21u)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_rays, d_out21, n);
     return static_cast<int>(hipGetLastError());
 }
 

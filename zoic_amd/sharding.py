@@ -5,8 +5,9 @@ bit-identical to the single-GPU frame.  The one exchange is the gather of the fi
 (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU in the tests).
 
 The gather is pipelined against the trace: a rank cuts its slab into sub-launches of about `chunk_bytes`
-of payload; as soon as sub-launch k is queued, its 28-byte payload (origin, dir, weight -- the flag word stays home)
-is posted to the root on the communication stream while sub-launch k+1 traces.  xGMI is point to point: every
+of payload, queued alternately on two compute streams (the end of one sub-launch -- its drain and the STRICT kernel over
+its work list -- runs under the next one's trace); as soon as sub-launch k is queued, its 28-byte payload (origin, dir,
+weight -- the flag word stays home) is posted to the root on the communication stream while sub-launch k+1 traces.  xGMI is point to point: every
 peer -> root transfer rides its own link, so the root ingests on up to 7 links at once; all sends/recvs of one round
 are posted as ONE batch_isend_irecv group (a single ncclGroupStart/End on RCCL).
 """
@@ -84,6 +85,12 @@ class ShardedFrame:
             chunk_bytes = max(min_chunk_bytes, (slab_bytes + chunks_per_slab - 1) // chunks_per_slab)
         self.chunk_bytes = chunk_bytes
         chunk_rays = max(tile, chunk_bytes // (4 * payload_floats))
+        if self.world == 1:
+            # nothing to gather, hence nothing to overlap: the slab is ONE launch.  Sub-launches are not free -- each pays its
+            # start and its drain, and a contiguous quarter of a frame is more uniform than the frame (C5: the corner rows are
+            # dead pixels, bound by HBM, the middle rows by instruction issue; one launch interleaves them through its eight
+            # partition cursors, four row-wise sub-launches run them one after the other: 70 -> 61 Grays/s on one GPU)
+            chunk_rays = max(chunk_rays, n_total)
         # every rank cuts its slab the same way, so the root knows each peer's message sizes without a handshake
         self.chunks = [chunks_of_slab(a, b, chunk_rays, tile) for a, b in self.slabs]
         self.rounds = max(len(c) for c in self.chunks)
@@ -94,43 +101,62 @@ class ShardedFrame:
         self.stage = [torch.empty((biggest, self.k), dtype=torch.float32, device=device) for _ in range(2)] if self.rank != dst else None
         self.cuda = device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=device) if self.cuda else None
+        # Sub-launches alternate between TWO compute streams: a Kolb launch ends with a drain (the pool's last rays at a few
+        # lanes per pass) and, in the decision-safe mode, with the STRICT kernel over its work list (a latency floor of
+        # ~0.1 ms); back to back on one stream, four sub-launches pay that four times (13-14 % of a C4 / C5 slab on one GPU in
+        # round 2).  On alternating streams sub-launch k + 1 traces under the end of sub-launch k (every launch owns its
+        # work cursors and work list: capi.cpp launch slots).
+        self.compute_streams = [torch.cuda.Stream(device=device) for _ in range(2)] if self.cuda else None
+        self.slots = 3          # generate() may rotate this many record buffers: chunk k may only overwrite chunk k - 3's
+        self.slot_free = [None] * self.slots
 
     def run(self, gather=True):
         """Render this rank's slab chunk by chunk; with gather=True the payload of chunk k travels while chunk k+1 is
         traced.  Returns the root's full (n_total, 7) tensor (None on the other ranks, or when gather=False)."""
+        import contextlib
         torch, dist = self.torch, self.dist
         mine = self.chunks[self.rank]
         pending = []
         stage_busy = [None, None]   # the sends still reading each staging buffer
+        caller = torch.cuda.current_stream(self.device) if self.cuda else None
+        if self.cuda:
+            for cs in self.compute_streams:
+                cs.wait_stream(caller)           # the samples (and whatever else the caller queued) come first
         for k in range(self.rounds):
-            rec = None
-            if k < len(mine):
-                a, b = mine[k]
-                rec = self.generate(a, b)               # queued on the current (compute) stream, asynchronous on a GPU
-            if not gather:
-                continue
-            ops = []
-            if self.rank == self.dst:
-                if rec is not None:
-                    self.full[a:b].copy_(rec[:, :self.k])
-                for r in range(self.world):
-                    if r != self.dst and k < len(self.chunks[r]):
-                        ra, rb = self.chunks[r][k]
-                        ops.append(dist.P2POp(dist.irecv, self.full[ra:rb], r))
-            elif rec is not None:
-                buf = self.stage[k & 1][: b - a]
-                if stage_busy[k & 1] is not None:
-                    for q in stage_busy[k & 1]:         # the send that used this staging buffer two rounds ago
-                        q.wait()
-                    pending.remove(stage_busy[k & 1])   # a gloo send request must be waited for exactly once
-                    stage_busy[k & 1] = None
-                buf.copy_(rec[:, :self.k])             # 32-byte records -> 28-byte payload, on the compute stream
-                ops.append(dist.P2POp(dist.isend, buf, self.dst))
+            cs = self.compute_streams[k & 1] if self.cuda else None
+            with (torch.cuda.stream(cs) if self.cuda else contextlib.nullcontext()):
+                rec = None
+                if k < len(mine):
+                    a, b = mine[k]
+                    if self.cuda and self.slot_free[k % self.slots] is not None:
+                        cs.wait_event(self.slot_free[k % self.slots])   # the record buffer's previous chunk has been packed
+                    rec = self.generate(a, b)           # queued on this chunk's compute stream, asynchronous on a GPU
+                ops = []
+                if gather and self.rank == self.dst:
+                    if rec is not None:
+                        self.full[a:b].copy_(rec[:, :self.k])
+                    for r in range(self.world):
+                        if r != self.dst and k < len(self.chunks[r]):
+                            ra, rb = self.chunks[r][k]
+                            ops.append(dist.P2POp(dist.irecv, self.full[ra:rb], r))
+                elif gather and rec is not None:
+                    buf = self.stage[k & 1][: b - a]
+                    if stage_busy[k & 1] is not None:
+                        for q in stage_busy[k & 1]:         # the send that used this staging buffer two rounds ago
+                            q.wait()                        # (on a GPU: this chunk's compute stream waits for it)
+                        pending.remove(stage_busy[k & 1])   # a gloo send request must be waited for exactly once
+                        stage_busy[k & 1] = None
+                    buf.copy_(rec[:, :self.k])             # 32-byte records -> 28-byte payload, on the chunk's compute stream
+                    ops.append(dist.P2POp(dist.isend, buf, self.dst))
+                if self.cuda and rec is not None:
+                    ev = self.slot_free[k % self.slots] or torch.cuda.Event()
+                    ev.record(cs)
+                    self.slot_free[k % self.slots] = ev
             if ops:
                 if self.cuda:
-                    # post the round on the communication stream, behind the compute work queued so far: RCCL moves
-                    # chunk k while the next iteration's kernel runs on the compute stream
-                    self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                    # post the round on the communication stream, behind this chunk's compute work: RCCL moves chunk k
+                    # while the next sub-launch runs on the other compute stream
+                    self.comm_stream.wait_stream(cs)
                     with torch.cuda.stream(self.comm_stream):
                         reqs = dist.batch_isend_irecv(ops)
                 else:
@@ -141,6 +167,9 @@ class ShardedFrame:
         for reqs in pending:
             for q in reqs:
                 q.wait()
-        if gather and self.cuda:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if self.cuda:
+            for cs in self.compute_streams:
+                caller.wait_stream(cs)
+            if gather:
+                caller.wait_stream(self.comm_stream)
         return self.full if gather else None
