@@ -5,25 +5,24 @@
 
 One "step" = one pass of camera_create_ray over one full frame of synthetic samples (config C3 by default:
 F_2.0_DOUBLE_GAUSS + image-based bokeh sampler, 3840x2160x16spp = 132,710,400 samples), samples already resident
-in HBM, rays written to HBM.  Rank 0 prints ONE JSON line:
+in HBM, rays written to HBM.  Rank 0 prints ONE JSON line (kept under 6 KB: what a field means is said once, in `notes`):
 
   value / ms_per_step   the headline workload, K timed steps between barriers.  N>1 (torch.distributed.run, one rank per
                         GPU): every rank renders its own frame of the headline size -- the path shards by independent
                         samples with no data-path collective, so this is weak scaling;
-  roofline              the dominant kernel against the HBM roofline (per the bench contract) + valu_roofline, the bound
-                        that actually binds the Kolb kernels (instruction issue);
-  configs               the other BASELINE.json configs at their true sizes (C1, C2, C4, C5 fast + C3 strict), each
-                        with rate, kernel time, roofline and a parity block -- parity cases, measured so that every
-                        number quoted in DESIGN.md is a driver record;
-  sharded_frame         BASELINE.json configs 4/5 as north_star states them: ONE C4 / C5 frame cut into ray-index slabs
-                        over the N ranks, compute-only and with the RCCL gather of the 28-byte payload on rank 0
-                        (chunked, overlapped with the trace);
-  host_path             the PCIe-inclusive rate of the host-buffer entry point (never `value`);
+  roofline              the launch against the HBM roofline (per the bench contract), kernel time by HIP events on the launch
+                        stream, + the VALU-issue figures of the bound that actually binds the Kolb kernels;
+  parity                direction RMSE / decision flips of the benchmarked mode against the oracle;
+  configs               the other BASELINE.json configs at their true sizes (C1, C2, C4, C5 fast + C3 strict);
+  sharded_frame         BASELINE.json configs 4/5 as north_star states them: ONE C4 / C5 frame in ray-index slabs over the N
+                        ranks, compute-only and with the RCCL gather of the 28-byte payload on rank 0;
+  host_path             PCIe-inclusive rates of the host-buffer entry points (never `value`) and the per-sample call latency;
   cpu_baseline          the oracle timed on this box's host cores (N=1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,8 +34,25 @@ ALGO_BYTES_PER_RAY = 48  # 16 B sample in + one 32 B ray record out (28 B origin
 SURVEY_BYTES_PER_RAY = 44  # SURVEY 8(d)'s figure (16 + 28): reported next to it
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 VALU_PEAK_ARCH_TWIPS = 1.2288   # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md "Wave scheduling")
-VALU_PEAK_MEASURED_TWIPS = 0.95  # plain-f32 / mixed streams at >= 4 waves/SIMD, clocks as they sag under load (tools/ubench/op_rate.hip, profiles/ubench_r01.txt)
 CPU_SLAB_RAYS = 16_588_800       # the fixed slab (= config 2's full size) the CPU legs are quoted on
+
+NOTES = {
+    "roofline": "achieved = 48 B/ray (16 B sample + 32 B record) x rays / kernel_ms; kernel_ms = the launch (main kernel + STRICT kernel over "
+                "its work list) by HIP events on the launch stream; frac44 = the same at SURVEY 8(d)'s 44 B/ray; traffic, lane_instr, "
+                "lane_util = committed rocprofv3 PMC run of this (config, mode), profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE), "
+                "not measured in this process; valu_frac = wave64 VALU instr/s over 1024 SIMDs x 2.4 GHz / 2; the Kolb kernels are "
+                "bound by VALU issue, the thin lens (C1) by HBM",
+    "mode": "fast = ZOIC_PRECISION_FAST: f32 without the reference's scattered f64 intermediates, decisions at ill-conditioned "
+            "interfaces re-taken in STRICT (flips = rays whose try count / weight differs from the oracle's); strict = bit-exact",
+    "parity": "256 Ki samples from the middle of the frame against the oracle (CPU restatement of zoic.cpp); rmse over rays with "
+              "identical history and weight != 0; north-star tolerance 1e-5",
+    "sharded_frame": "one frame in ray-index slabs; on one GPU there is nothing to gather and a slab is ONE launch",
+    "host_path": "zoic_create_rays_host / _arnold end to end over PCIe, 16.8 M samples; per_sample = zoic_camera_create_ray "
+                 "(resident mailbox kernel) timed by tools/native/sample_latency.c",
+    "cpu_baseline": "the oracle on this box's host cores, page-touched buffers, >= 3 repetitions of >= 3 s; one_thread = the "
+                    "sequential process-global xor128 (the configuration the reference is validated in); scaling_efficiency = all / "
+                    "(one x cores); BASELINE.md: the true reference does 0.6-1.0 Mrays/s per thread",
+}
 
 
 def parse_args():
@@ -45,8 +61,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
-    ap.add_argument("--precision", default=os.environ.get("ZOIC_BENCH_PRECISION", "fast"), choices=["fast", "unchecked", "strict"],
-                    help="fast = ZOIC_PRECISION_FAST (decision-safe), unchecked = ZOIC_PRECISION_FAST_UNCHECKED (round 1's fast), strict = bit-exact")
+    ap.add_argument("--precision", default="fast", choices=["fast", "unchecked", "strict"],
+                    help="fast = ZOIC_PRECISION_FAST (decision-safe), unchecked = ZOIC_PRECISION_FAST_UNCHECKED, strict = bit-exact")
     ap.add_argument("--rays", type=int, default=0, help="override the per-GPU sample count of the headline workload (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -54,7 +70,7 @@ def parse_args():
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-frame (north-star configs 4/5) measurement")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target wall time of each CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of one repetition of a CPU baseline leg")
     ap.add_argument("--gather-chunk-mb", type=int, default=0, help="payload MB per gather chunk (0: a quarter of a slab, at least 64 MB)")
     return ap.parse_args()
 
@@ -82,35 +98,69 @@ def make_oracle(cfg_name):
 
 
 # ------------------------------------------------------------------------------------------------- CPU legs
+def usable_cores():
+    """Threads this process can really run at once: the affinity mask, capped by the container's CPU quota (cgroup cpu.max;
+    the GPU boxes of this pool grant 16 CPUs of a 256-thread host -- 256 threads would only time the throttle)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return n
+
+
 def cpu_baseline(cfg_name, seconds):
-    """The oracle (plain-C restatement of zoic.cpp) timed on this box's host cores.  Two legs:
-    (i) ONE thread drawing retries from the sequential process-global xor128 -- the configuration the reference is
-    validated in; (ii) all host cores with per-ray retry streams (the reference's shared stream is a data race).
-    Both on the first rays of the fixed 16,588,800-ray slab of this config, bounded to about `seconds` each.
-    Baseline only -- never part of `value`."""
+    """The oracle (plain-C restatement of zoic.cpp) timed on this box's host cores.  Two legs: ONE thread drawing
+    retries from the sequential process-global xor128, and all host cores with per-ray retry streams (the reference's shared
+    stream is a data race), dynamic 4096-ray chunks.  Both on the first rays of the fixed 16,588,800-ray slab of this config,
+    into buffers whose pages have been touched, 3 repetitions of >= `seconds` each (best one reported).  Baseline only."""
+    import numpy as np
     from zoic_amd.workloads import CONFIGS, ray_rng_states, synthetic_samples
     c = CONFIGS[cfg_name]
     oc = make_oracle(cfg_name)
-    cores = os.cpu_count() or 1
+    hw = os.cpu_count() or 1
+    cores = usable_cores()
     slab = min(CPU_SLAB_RAYS, c["width"] * c["height"] * c["spp"])
     gen = lambda n: synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1, ray_index_base=0)  # noqa: E731
-    probe_n = 1 << 17
+
+    def leg(n, threads):
+        s = gen(n)
+        st = ray_rng_states(n, seed=1, ray_index_base=0) if threads > 1 else None
+        out = (np.zeros((7, n), np.float32), np.zeros(n, np.uint8))
+        run = lambda: oc.create_rays(s, rng_states=st, threads=threads, out=out)  # noqa: E731
+        run()                                                   # touches every page, warms the caches, starts the clocks
+        best, reps = 0.0, []
+        for _ in range(3):
+            calls, t0 = 0, time.perf_counter()
+            while True:
+                if threads == 1:
+                    oc.reset_rng()
+                run()
+                calls += 1
+                dt = time.perf_counter() - t0
+                if dt >= seconds:
+                    break
+            reps.append(n * calls / dt)
+            best = max(best, reps[-1])
+        return best, reps
+    probe_n = 1 << 16
     s = gen(probe_n)
     t0 = time.perf_counter()
     oc.create_rays(s)
-    probe_rate = probe_n / (time.perf_counter() - t0)
-    n1 = int(min(slab, max(probe_n, probe_rate * seconds)))
-    s = gen(n1)
-    oc.reset_rng()
-    t0 = time.perf_counter()
-    oc.create_rays(s)                                            # rng_states=None: the sequential global stream
-    one = n1 / (time.perf_counter() - t0)
-    n_all = int(min(slab, max(probe_n, one * cores * seconds * 0.6)))
-    s = gen(n_all)
-    st = ray_rng_states(n_all, seed=1, ray_index_base=0)
-    t0 = time.perf_counter()
-    oc.create_rays(s, rng_states=st, threads=cores)
-    dt = time.perf_counter() - t0
+    rate1 = probe_n / (time.perf_counter() - t0)
+    n1 = int(min(slab, max(probe_n, rate1 * min(seconds, 1.0))))
+    one, _ = leg(n1, 1)
+    n_all = int(min(slab, max(1 << 20, one * cores * 0.25)))     # about a quarter of a second of the whole machine per call
+    allc, reps = leg(n_all, cores)
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -119,12 +169,10 @@ def cpu_baseline(cfg_name, seconds):
                 break
     except OSError:
         pass
-    return {"value": round(n_all / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "first %d rays of %s's %d-ray slab, all %d host threads, per-ray retry streams" % (n_all, cfg_name, slab, cores),
-            "one_thread_value": round(one / 1e6, 4), "one_thread_rays": n1, "one_thread_rng": "sequential process-global xor128 (zoic.cpp:647-652)",
-            "slab_rays": slab, "all_cores_rays": n_all, "cpu_model": model,
-            "calibration": "BASELINE.md section 2 (true reference, survey container, 1 thread): DOUBLE_GAUSS+LUT 0.75-0.8, TESSAR 1.0, "
-                           "FISHEYE 0.8, PETZVAL 0.6-0.7, thin lens 20 Mrays/s"}
+    return {"value": round(allc / 1e6, 2), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "first %d rays of %s's %d-ray slab per call, %d threads (CPU quota of this container; the host has %d)" % (n_all, cfg_name, slab, cores, hw),
+            "one_thread": round(one / 1e6, 4), "one_thread_rays": n1, "scaling_efficiency": round(allc / (one * cores), 3),
+            "repetitions": [round(r / 1e6, 1) for r in reps], "cpu": model}
 
 
 def parity_probe(cam, cfg_name, precision):
@@ -137,26 +185,21 @@ def parity_probe(cam, cfg_name, precision):
     base = (c["width"] * (c["height"] // 2)) * c["spp"]
     s = synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1, ray_index_base=base)
     st = ray_rng_states(n, seed=1, ray_index_base=base)
-    ref = make_oracle(cfg_name).create_rays(s, rng_states=st, threads=os.cpu_count() or 1)
+    ref = make_oracle(cfg_name).create_rays(s, rng_states=st, threads=usable_cores())
     got = cam.create_rays(s, ray_index_base=base)
     same = (got["flags"] == ref["flags"])
     live = same & (ref["weight"] != 0)
     dd = (got["dir"][:, live].astype(np.float64) - ref["dir"][:, live].astype(np.float64))
-    do = (got["origin"][:, live].astype(np.float64) - ref["origin"][:, live].astype(np.float64))
-    return {"vs": "oracle (CPU restatement of zoic.cpp)", "samples": n, "mode": precision,
-            "dir_rmse": float(np.sqrt((dd ** 2).sum(0).mean())) if live.any() else 0.0,
-            "origin_rmse": float(np.sqrt((do ** 2).sum(0).mean())) if live.any() else 0.0,
-            "decision_flip_frac": float((~same).mean()),
-            "bit_exact": bool(np.array_equal(got["planes"].view(np.uint32), ref["planes"].view(np.uint32))
-                              and np.array_equal(got["flags"], ref["flags"]))}
+    return {"rmse": float("%.3g" % np.sqrt((dd ** 2).sum(0).mean())) if live.any() else 0.0,
+            "flips": float("%.3g" % (~same).mean()),
+            "bit_exact": bool(np.array_equal(got["planes"].view(np.uint32), ref["planes"].view(np.uint32)) and np.array_equal(got["flags"], ref["flags"]))}
 
 
 # ------------------------------------------------------------------------------------------------- GPU legs
 def pmc_entry(cfg_name, precision):
     """HBM bytes and VALU instruction counts of the last committed rocprofv3 PMC run of this (config, mode)."""
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(tpath)).get("%s_%s" % (cfg_name, precision)) or None
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s_%s" % (cfg_name, precision)) or None
     except Exception:
         return None
 
@@ -164,27 +207,16 @@ def pmc_entry(cfg_name, precision):
 def roofline_block(cfg_name, precision, n, kernel_ms, thin):
     achieved = ALGO_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9
     ent = pmc_entry(cfg_name, precision)
-    kernel = "thin_rays_kernel" if thin else {"fast": "kolb_refill_guard_kernel (+ heavy-list and strict redo kernels of the launch)",
-                                              "unchecked": "kolb_refill_fast_kernel", "strict": "kolb_refill_strict_kernel"}[precision]
-    roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": ent.get("hbm_bytes_per_launch") if ent else None,
-            "traffic_source": (ent.get("source", "committed rocprofv3 run") + " -- replayed from the committed PMC run, not measured in this process")
-            if ent else "no committed PMC run for this (config, mode)",
-            "kernel": kernel, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_ray": ALGO_BYTES_PER_RAY,
-            "frac_at_survey_44B": round(SURVEY_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            "note": "HBM fraction per the bench contract; the Kolb kernels are bound by VALU instruction issue (valu_roofline)" if not thin
-            else "thin lens is HBM-bound"}
-    valu = None
-    if ent and ent.get("lane_instr_per_ray"):
+    roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": round(ent["hbm_bytes_per_launch"]) if ent else None, "kernel_ms": round(kernel_ms, 4),
+            "frac44": round(SURVEY_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel": "thin_rays_kernel" if thin else {"fast": "kolb_pool_guard_kernel + kolb_pool_strict_listed_kernel", "unchecked": "kolb_pool_fast_kernel",
+                                                        "strict": "kolb_pool_strict_kernel"}[precision]}
+    if ent and ent.get("lane_instr_per_ray") and not thin:
         rate = ent["lane_instr_per_ray"] / 64.0 * n / (kernel_ms * 1e-3) / 1e12
-        valu = {"bound": "valu-issue", "achieved": round(rate, 4), "unit": "T wave64-instr/s",
-                "peak": VALU_PEAK_ARCH_TWIPS, "frac": round(rate / VALU_PEAK_ARCH_TWIPS, 4),
-                "peak_measured": VALU_PEAK_MEASURED_TWIPS, "frac_of_measured": round(rate / VALU_PEAK_MEASURED_TWIPS, 4),
-                "lane_instr_per_ray": round(ent["lane_instr_per_ray"], 1), "lane_utilisation": round(ent.get("valu_thread_util", 0.0), 3),
-                "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles; peak_measured = tools/ubench/op_rate.hip on MI355X (clocks sag to ~1.8 GHz "
-                        "under dense FMA); instruction count replayed from the committed PMC run"}
-    return roof, valu
+        roof.update(lane_instr=round(ent["lane_instr_per_ray"]), lane_util=round(ent.get("valu_thread_util", 0.0), 3),
+                    valu_frac=round(rate / VALU_PEAK_ARCH_TWIPS, 3))
+    return roof
 
 
 def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_rank=0):
@@ -201,7 +233,7 @@ def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_ra
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for k in range(steps):
-        ev[k][0].record()                      # torch's current stream == the stream the kernel is launched on
+        ev[k][0].record()                      # torch's current stream == the stream the kernels are launched on
         cam.create_rays(samples, ray_index_base=base, out=out)
         ev[k][1].record()
     torch.cuda.synchronize()
@@ -218,6 +250,10 @@ def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_ra
     return elapsed, kernel_ms
 
 
+def frame_stats(counters, n_done):
+    return round(counters["vignettedRays"] / max(n_done, 1), 5)
+
+
 def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, parity):
     from zoic_amd.workloads import CONFIGS, ray_count
     cfg = CONFIGS[cfg_name]
@@ -225,16 +261,16 @@ def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, par
     cam = make_camera(cfg_name, precision, local_rank)
     elapsed, kernel_ms = time_frame(torch, cam, cfg, n, 0, steps, warmup, dev)
     counters = cam.counters()
-    done = counters["succesRays"] + counters["vignettedRays"]
     thin = cfg["params"]["lensModel"] == 0
-    roof, valu = roofline_block(cfg_name, precision, n, kernel_ms, thin)
-    ent = {"config": cfg_name, "workload": cfg["desc"], "precision_mode": precision, "rays": n, "steps": steps,
-           "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "roofline": roof, "zero_weight_frac": round(counters["vignettedRays"] / max(done, 1), 5)}
-    if valu:
-        ent["valu_roofline"] = valu
+    roof = roofline_block(cfg_name, precision, n, kernel_ms, thin)
+    ent = {"config": cfg_name, "mode": precision, "rays": n, "steps": steps, "value": round(n * steps / elapsed / 1e6, 1),
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "kernel_ms": roof["kernel_ms"], "hbm_frac": roof["frac"],
+           "zero_weight": frame_stats(counters, counters["succesRays"] + counters["vignettedRays"])}
+    for k in ("traffic", "lane_instr", "lane_util", "valu_frac"):
+        if roof.get(k) is not None:
+            ent[k] = roof[k]
     if parity:
-        ent["parity"] = parity_probe(cam, cfg_name, precision)
+        ent.update(parity_probe(cam, cfg_name, precision))
     cam.close()
     torch.cuda.empty_cache()
     return ent
@@ -252,11 +288,11 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
     lo, hi = frame.slabs[rank]
     samples = cam.generate_samples(hi - lo, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=lo)
     biggest = max((b - a for a, b in frame.chunks[rank]), default=0)
-    recs = [dict(rays=torch.empty((biggest, 8), dtype=torch.float32, device=dev)) for _ in range(3)]
+    recs = [dict(rays=torch.empty((biggest, 8), dtype=torch.float32, device=dev)) for _ in range(min(frame.slots, max(1, len(frame.chunks[rank]))))]
     turn = [0]
 
-    def generate(a, b):   # sub-launch over global rays [a, b) of this rank's slab; three record buffers rotate
-        o = recs[turn[0] % 3]
+    def generate(a, b):   # sub-launch over global rays [a, b) of this rank's slab; the record buffers rotate (ShardedFrame.slots)
+        o = recs[turn[0] % len(recs)]
         turn[0] += 1
         view = dict(rays=o["rays"][: b - a])
         cam.create_rays(samples[a - lo:b - lo], ray_index_base=a, out=view)
@@ -264,6 +300,7 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
     frame.generate = generate
 
     def timed(gather):
+        turn[0] = 0
         frame.run(gather=gather)
         torch.cuda.synchronize()
         if world > 1:
@@ -271,6 +308,7 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
+            turn[0] = 0
             frame.run(gather=gather)
         torch.cuda.synchronize()
         if world > 1:
@@ -284,15 +322,13 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
         return el
     t_compute = timed(False)
     t_gather = timed(True) if world > 1 else None
-    ent = {"config": cfg_name, "workload": cfg["desc"], "rays": n_total, "n_gpus": world, "steps": steps, "scaling": "strong",
-           "parallelism": "one frame in %d ray-index slabs, %d sub-launches per slab" % (world, len(frame.chunks[rank])),
-           "compute_only": {"value": round(n_total * steps / t_compute / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(t_compute / steps * 1e3, 4)}}
+    ent = {"config": cfg_name, "rays": n_total, "n_gpus": world, "steps": steps, "scaling": "strong", "sub_launches_per_slab": len(frame.chunks[rank]),
+           "compute_only": round(n_total * steps / t_compute / 1e6, 1), "compute_ms": round(t_compute / steps * 1e3, 3)}
     if t_gather is not None:
         payload = 4 * PAYLOAD_FLOATS
-        ent["with_gather"] = {"value": round(n_total * steps / t_gather / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(t_gather / steps * 1e3, 4),
-                              "gather": "28-byte payload of every peer slab -> rank 0, %d MB chunks, batch_isend_irecv on a second stream under the trace" % (frame.chunk_bytes >> 20),
-                              "bytes_into_root_per_frame": payload * (n_total - (frame.slabs[0][1] - frame.slabs[0][0])),
-                              "root_ingest_gb_s": round(payload * (n_total - (frame.slabs[0][1] - frame.slabs[0][0])) * steps / t_gather / 1e9, 1)}
+        into_root = payload * (n_total - (frame.slabs[0][1] - frame.slabs[0][0]))
+        ent.update(with_gather=round(n_total * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3), chunk_mb=frame.chunk_bytes >> 20,
+                   root_ingest_gb_s=round(into_root * steps / t_gather / 1e9, 1))
         # rank 0 holds the gathered frame: a peer's chunk must equal what this GPU computes for the same global rays
         full = frame.run(gather=True)
         torch.cuda.synchronize()
@@ -300,40 +336,63 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
             a, b = frame.chunks[world - 1][-1]
             s = cam.generate_samples(b - a, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=a)
             mine = cam.create_rays(s, ray_index_base=a)["rays"][:, :PAYLOAD_FLOATS]
-            ent["with_gather"]["bit_identical_to_single_gpu"] = bool(torch.equal(mine.contiguous().view(torch.int32), full[a:b].view(torch.int32)))
-    else:
-        ent["with_gather"] = None
-        ent["note"] = "one GPU: nothing to gather"
+            ent["bit_identical_to_single_gpu"] = bool(torch.equal(mine.contiguous().view(torch.int32), full[a:b].view(torch.int32)))
     cam.close()
     del samples, recs, frame
     torch.cuda.empty_cache()
     return ent
 
 
+def per_sample_latency():
+    """zoic_camera_create_ray as a render thread sees it (tools/native/sample_latency.c, built by __graft_entry__.build())."""
+    exe = os.path.join(ROOT, "tools", "native", "sample_latency")
+    lens = os.path.join(ROOT, "zoic_amd", "lenses", "double_gauss_f2.0.dat")
+    if not os.path.exists(exe):
+        return {"error": "tools/native/sample_latency not built"}
+    res = {}
+    for key, threads, precision in (("fast_1_thread", 1, 1), ("strict_1_thread", 1, 0), ("fast_16_threads", 16, 1)):
+        try:
+            out = subprocess.run([exe, lens, str(threads), "40000", str(precision), "1"], capture_output=True, text=True, timeout=120)
+            j = json.loads(out.stdout.strip().splitlines()[-1])
+            res[key] = {"median_us": j["median_us"], "p99_us": j["p99_us"], "calls_per_s": round(j["calls_per_s"])}
+        except Exception as e:  # noqa: BLE001
+            res[key] = {"error": repr(e)[:80]}
+    return res
+
+
 def host_path_entry(cam, cfg):
-    """zoic_create_rays_host end to end (H2D + trace + D2H over PCIe), pageable and page-locked caller buffers."""
+    """The host-buffer entry points end to end (H2D + trace + D2H over PCIe), pageable and page-locked caller buffers."""
     import numpy as np
     from zoic_amd import PinnedArray, _capi
     from zoic_amd.workloads import synthetic_samples
+    import ctypes as C
     n = 1 << 24
     s = synthetic_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1)
-    res = {"rays": n, "note": "PCIe-inclusive; never reported as `value`"}
+    res = {"rays": n}
 
-    def timed(sp, rp):
+    def timed(call, bytes_per_ray):
         for _ in range(4):     # the PCIe link and the copy engines take a few transfers to reach their steady rate
-            cam._check(cam._lib.zoic_create_rays_host(cam._h, n, sp, None, 0, rp))
+            cam._check(call())
         t0 = time.perf_counter()
         for _ in range(3):
-            cam._check(cam._lib.zoic_create_rays_host(cam._h, n, sp, None, 0, rp))
+            cam._check(call())
         dt = (time.perf_counter() - t0) / 3
-        return {"value": round(n / dt / 1e6, 1), "unit": "Mrays/s", "pcie_gb_s_both_directions": round(48 * n / dt / 1e9, 1)}
+        return {"value": round(n / dt / 1e6, 1), "pcie_gb_s": round(bytes_per_ray * n / dt / 1e9, 1)}
     rays = np.empty(n, dtype=_capi.RAY_DTYPE)
-    res["pageable"] = timed(s.ctypes.data, rays.ctypes.data)
+    res["pageable"] = timed(lambda: cam._lib.zoic_create_rays_host(cam._h, n, s.ctypes.data, None, 0, rays.ctypes.data), 48)
     ps, pr = PinnedArray((n, 4), np.float32), PinnedArray((n,), _capi.RAY_DTYPE)
     ps.array[:] = s
-    res["pinned"] = timed(ps.array.ctypes.data, pr.array.ctypes.data)
+    res["pinned"] = timed(lambda: cam._lib.zoic_create_rays_host(cam._h, n, ps.array.ctypes.data, None, 0, pr.array.ctypes.data), 48)
     ps.free()
     pr.free()
+    # AtCameraInput (28 B) -> AtCameraOutput (84 B) rows, page-locked caller arrays
+    pi, po = PinnedArray((n, 7), np.float32), PinnedArray((n, 21), np.float32)
+    pi.array[:] = 0.0
+    pi.array[:, 0], pi.array[:, 1], pi.array[:, 4], pi.array[:, 5] = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
+    res["arnold_layout"] = timed(lambda: cam._lib.zoic_create_rays_arnold(cam._h, n, pi.array.ctypes.data_as(C.POINTER(_capi.CameraInput)),
+                                                                          po.array.ctypes.data_as(C.POINTER(_capi.CameraOutput)), 0), 112)
+    pi.free()
+    po.free()
     return res
 
 
@@ -352,7 +411,7 @@ def main():
     torch.cuda.set_device(local_rank)      # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("ZOIC_FORCE_DIST"):   # ZOIC_FORCE_DIST: exercise the RCCL path on one GPU
+    if world > 1 or os.environ.get("ZOIC_FORCE_DIST"):   # ZOIC_FORCE_DIST: initialise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -370,29 +429,25 @@ def main():
     line = None
     if rank == 0:
         counters = cam.counters()
-        done = counters["succesRays"] + counters["vignettedRays"]
         thin = cfg["params"]["lensModel"] == 0
-        roof, valu = roofline_block(args.config, args.precision, n, kernel_ms, thin) if not args.rays else \
-            roofline_block("none", args.precision, n, kernel_ms, thin)
         line = {
             "metric": "camera rays/sec (Mrays/s), 4K x 16spp Kolb lens trace; ray-dir RMSE vs CPU ref",
             "value": round(n_total * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.config, cfg["desc"]), "rays_per_gpu_per_step": n,
-                       "precision_mode": args.precision + (" (decision-safe: try counts, weights, flags and counters are the reference's)" if args.precision == "fast" else ""),
+            "config": {"workload": "%s: %s" % (args.config, cfg["desc"]), "rays_per_gpu_per_step": n, "precision_mode": args.precision,
                        "parallelism": "independent frames per GPU (dp%d), no data-path collective" % world},
-            "roofline": roof,
-            "zero_weight_frac": round(counters["vignettedRays"] / max(done, 1), 5),
+            "roofline": roofline_block(args.config if not args.rays else "none", args.precision, n, kernel_ms, thin),
+            "zero_weight": frame_stats(counters, counters["succesRays"] + counters["vignettedRays"]),
         }
-        if valu:
-            line["valu_roofline"] = valu
         if not args.no_parity:
             line["parity"] = parity_probe(cam, args.config, args.precision)
         if not args.no_host_path:
             line["host_path"] = host_path_entry(cam, cfg)
     cam.close()
     torch.cuda.empty_cache()
+    if rank == 0 and not args.no_host_path:
+        line["host_path"]["per_sample"] = per_sample_latency()
 
     if not args.no_configs and world == 1:
         ents = []
@@ -414,7 +469,12 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        line["notes"] = NOTES
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text) > 6000:     # the driver keeps the tail of the line: what explains goes first, the numbers stay
+            del line["notes"]
+            text = json.dumps(line, separators=(",", ":"))
+        print(text, flush=True)
     if dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

@@ -164,12 +164,18 @@ class OracleCamera:
         r = self._L.zo_camera_rng(self._h).contents
         return (r.x, r.y, r.z, r.w)
 
-    def create_rays(self, samples, rng_states=None, want_first_retry_states=False, threads=0):
-        """samples: (n,4) float32 (sx, sy, lensx, lensy).  Returns dict of planes + flags."""
+    def create_rays(self, samples, rng_states=None, want_first_retry_states=False, threads=0, out=None):
+        """samples: (n,4) float32 (sx, sy, lensx, lensy).  Returns dict of planes + flags.
+        out: (planes (7,n) float32, flags (n,) uint8) to write into (timing runs reuse page-touched buffers)."""
         s = np.ascontiguousarray(samples, dtype=np.float32)
         n = s.shape[0]
-        planes = np.zeros((7, n), dtype=np.float32)
-        flags = np.zeros(n, dtype=np.uint8)
+        if out is not None:
+            planes, flags = out
+            assert planes.shape == (7, n) and planes.dtype == np.float32 and planes.flags.c_contiguous
+            assert flags.shape == (n,) and flags.dtype == np.uint8
+        else:
+            planes = np.zeros((7, n), dtype=np.float32)
+            flags = np.zeros(n, dtype=np.uint8)
         rs = None
         if rng_states is not None:
             rs = np.ascontiguousarray(rng_states, dtype=np.uint32)

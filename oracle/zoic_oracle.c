@@ -1037,7 +1037,8 @@ void zo_create_rays(zo_camera *cam, size_t n, const float *in4, float *planes, u
     }
 }
 
-typedef struct mt_job { zo_camera *cam; size_t n, lo, hi; const float *in4; float *planes; uint8_t *flags; const uint32_t *rng; int succ, vign, tir; } mt_job;
+typedef struct mt_job { zo_camera *cam; size_t n; size_t *next; const float *in4; float *planes; uint8_t *flags; const uint32_t *rng; int succ, vign, tir; } mt_job;
+#define ZO_MT_CHUNK 4096   /* rays a thread takes at a time: image regions differ in cost, equal slabs would leave cores idle */
 
 static void *mt_worker(void *arg)
 {
@@ -1046,9 +1047,14 @@ static void *mt_worker(void *arg)
      * tables are shared read-only */
     zo_camera local = *j->cam;
     local.lens.succesRays = local.lens.vignettedRays = local.lens.totalInternalReflection = 0;
-    for (size_t i = j->lo; i < j->hi; ++i) {
-        zo_rng r = { j->rng[4 * i], j->rng[4 * i + 1], j->rng[4 * i + 2], j->rng[4 * i + 3] };
-        one_ray(&local, j->n, i, j->in4, j->planes, j->flags, &r, NULL);
+    for (;;) {
+        const size_t lo = __atomic_fetch_add(j->next, (size_t)ZO_MT_CHUNK, __ATOMIC_RELAXED);
+        if (lo >= j->n) break;
+        const size_t hi = lo + ZO_MT_CHUNK < j->n ? lo + ZO_MT_CHUNK : j->n;
+        for (size_t i = lo; i < hi; ++i) {
+            zo_rng r = { j->rng[4 * i], j->rng[4 * i + 1], j->rng[4 * i + 2], j->rng[4 * i + 3] };
+            one_ray(&local, j->n, i, j->in4, j->planes, j->flags, &r, NULL);
+        }
     }
     j->succ = local.lens.succesRays; j->vign = local.lens.vignettedRays; j->tir = local.lens.totalInternalReflection;
     return NULL;
@@ -1060,8 +1066,9 @@ void zo_create_rays_mt(zo_camera *cam, size_t n, const float *in4, float *planes
     if (nthreads < 1) nthreads = 1;
     pthread_t *th = malloc(sizeof(pthread_t) * nthreads);
     mt_job *jobs = malloc(sizeof(mt_job) * nthreads);
+    size_t next = 0;
     for (int t = 0; t < nthreads; ++t) {
-        mt_job j = { cam, n, n * t / nthreads, n * (t + 1) / nthreads, in4, planes, flags, rng_states, 0, 0, 0 };
+        mt_job j = { cam, n, &next, in4, planes, flags, rng_states, 0, 0, 0 };
         jobs[t] = j;
         pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
     }

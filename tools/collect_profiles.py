@@ -18,12 +18,14 @@ with open(dst + "/pmc_counters.csv", "w", newline="") as fh:
 out = subprocess.check_output([sys.executable, "tools/pmc_summary.py", src, str(nrays)] + (["thin_r"] if ("thin" in tag or key.startswith("C1")) else []), text=True)
 open(dst + "/summary.txt", "w").write(out)
 shutil.copy(src + "/summary.json", dst + "/summary.json")
+if os.path.exists(src + "/bench_line.json"):
+    shutil.copy(src + "/bench_line.json", dst + "/bench_line.json")
 s = json.load(open(dst + "/summary.json"))
 tp = "profiles/pmc_traffic.json"
 t = json.load(open(tp)) if os.path.exists(tp) else {}
 t[key] = {"hbm_bytes_per_launch": s["hbm_bytes_per_launch"], "fetch_bytes_x2_corrected": s["fetch_bytes(x2 corrected)"],
           "write_bytes": s["write_bytes"], "lane_instr_per_ray": s["lane_instr_per_ray"], "valu_thread_util": s["valu_thread_util"],
-          "pipeline_us_per_launch": s.get("pipeline_us_per_launch"),
+          "pipeline_us_per_launch": s.get("pipeline_us_per_launch"), "dispatch_us": s.get("dispatch_us"),
           "source": dst + "/pmc_counters.csv (FETCH_SIZE x2 per MI355X_MICROARCH.md, separate --pmc passes; counters summed over the launch's kernel pipeline)"}
 json.dump(t, open(tp, "w"), indent=1)
 print(out)

@@ -11,7 +11,25 @@ if st:
         if pat in r["Name"]:
             print("%-66s calls %s avg_us %.1f" % (r["Name"][:66], r["Calls"], float(r["AverageNs"]) / 1e3))
             launch_us += float(r["AverageNs"]) / 1e3
-    print("pipeline per launch: %.1f us" % launch_us)
+    print("pipeline per launch (sum of kernel averages): %.1f us" % launch_us)
+# per-dispatch durations (kernel trace): median and minimum of every kernel of the launch over the TIMED dispatches (the last 20)
+dispatch = {}
+for f in glob.glob(base + "/trace/*/*_kernel_trace.csv"):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            per[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k, v in per.items():
+        v = sorted(v[-20:])
+        dispatch[k.split("(")[0].replace("void zoic::", "")] = {"dispatches": len(v), "median_us": round(v[len(v) // 2], 1), "min_us": round(v[0], 1), "max_us": round(v[-1], 1)}
+        print("%-60s %d timed dispatches: median %.1f min %.1f max %.1f us" % (k[:60], len(v), v[len(v) // 2], v[0], v[-1]))
+bench_line = None
+try:
+    bench_line = json.load(open(base + "/bench_line.json"))
+    print("bench line of the same call (no profiler): value %.1f Mrays/s, ms_per_step %.4f, kernel_ms %.4f" % (
+        bench_line["value"], bench_line["ms_per_step"], bench_line["roofline"]["kernel_ms"]))
+except Exception as e:
+    print("no bench line:", e)
 tot = {}
 for d in sorted(glob.glob(base + "/pmc*/*/*_counter_collection.csv")):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))     # counter -> kernel -> values
@@ -27,6 +45,9 @@ cyc = g("GRBM_GUI_ACTIVE") / 8
 simd = cyc * 1024
 out = {
     "pipeline_us_per_launch": launch_us,
+    "dispatch_us": dispatch,
+    "bench_line_same_call": {k: bench_line[k] for k in ("value", "ms_per_step")} if bench_line else None,
+    "dominant_kernel_median_fits_ms_per_step": (max(d["median_us"] for d in dispatch.values()) <= bench_line["ms_per_step"] * 1e3) if (bench_line and dispatch) else None,
     "vgpr/sgpr/lds (main kernel)": (tot.get("_vgpr"), tot.get("_sgpr"), tot.get("_lds")),
     "lane_instr_per_ray": g("SQ_INSTS_VALU") * 64 / nrays,
     "valu_thread_util": g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64),

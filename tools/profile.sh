@@ -1,13 +1,16 @@
 #!/bin/bash
 # tools/profile.sh <tag> [bench args...]  -- run on the GPU box (inside gpurun).  Writes gpurun_out/prof_<tag>/...
-# 1) kernel trace + stats (csv), 2..n) one PMC pass per counter group (never combined with sys/hip traces).
+# 0) the plain bench line of the same command (no profiler): bench_line.json -- the ms_per_step the profile must fit into;
+# 1) kernel trace + stats (csv) over 20 timed + 3 warm-up dispatches; 2..n) one PMC pass per counter group (never combined
+# with sys/hip traces; 5 dispatches each).
 set -u
 TAG=$1; shift
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+python bench.py --steps 20 --warmup 3 --only-headline $* 2> $OUT/bench_line.err | tail -1 > $OUT/bench_line.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 20 --warmup 3 --only-headline $* > $OUT/trace.log 2>&1
 BENCH="python bench.py --steps 5 --warmup 2 --only-headline $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 i=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" \
@@ -15,4 +18,3 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1 || echo "pmc group $i failed: $grp" >> $OUT/errors.txt
 done
-find $OUT -name "*.csv" | head -40
