@@ -21,6 +21,7 @@ int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const flo
 
 #ifdef ZOIC_PASS_STATS
 int read_pass_stats_dead(unsigned long long *acc8, int reset);
+int read_region_cycles_dead(unsigned long long *acc16, int reset);
 #endif
 
 }  // namespace zoic
@@ -31,5 +32,11 @@ extern "C" int zoic_debug_pass_stats(unsigned long long *out8, int reset)
     for (int i = 0; i < 8; ++i) out8[i] = 0;
     const int e = zoic::read_pass_stats(out8, reset);
     return e ? e : zoic::read_pass_stats_dead(out8, reset);
+}
+extern "C" int zoic_debug_region_cycles(unsigned long long *out16, int reset)
+{
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    const int e = zoic::read_region_cycles(out16, reset);
+    return e ? e : zoic::read_region_cycles_dead(out16, reset);
 }
 #endif

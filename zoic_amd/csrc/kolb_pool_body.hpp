@@ -177,12 +177,15 @@ __device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehT
 // Debug build only (-DZOIC_PASS_STATS, tools/pass_stats.py): pass statistics summed over all waves.  Not part of the product build.
 #ifdef ZOIC_PASS_STATS
 static __device__ unsigned long long g_passStats[8];   // A passes, B passes, search iterations, sum looking lanes, traces, sum cand lanes, sum active lanes, finished
-#define ZOIC_PS_DECL unsigned long long ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles per region of the pass loop, summed over all waves
+#define ZOIC_PS_DECL unsigned long long ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt[16] = {}, rtLast = __builtin_readcyclecounter();
 #define ZOIC_PS_ADD(I, V) ps[I] += (V);
-#define ZOIC_PS_FLUSH if (lane == 0) { for (int r = 0; r < 8; ++r) atomicAdd(&g_passStats[r], ps[r]); }
+#define ZOIC_MARK(N) { const unsigned long long rtNow = __builtin_readcyclecounter(); rt[N] += rtNow - rtLast; rtLast = rtNow; }
+#define ZOIC_PS_FLUSH if (lane == 0) { for (int r = 0; r < 8; ++r) atomicAdd(&g_passStats[r], ps[r]); for (int r = 0; r < 16; ++r) atomicAdd(&g_regionCycles[r], rt[r]); }
 #else
 #define ZOIC_PS_DECL
 #define ZOIC_PS_ADD(I, V)
+#define ZOIC_MARK(N)
 #define ZOIC_PS_FLUSH
 #endif
 
@@ -338,14 +341,16 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             }
             else return interface0_clear_fast<GUARD>(load_surface<false>(fsurf, 0), oo, dd, near0);
         };
+        ZOIC_MARK(0)   // loop top, flushes of the previous pass
         if (!fromPool) {
             // phase A: set 64 fresh rays up and run the search's FIRST step for all of them (zoic.cpp:1853-1925)
             active = lane < cnt1;
             idx = LISTED ? idx1 : base1 + lane;
-            const RaySetup rs = setup_ray<STRICT>(T, lutLds, s1.x, s1.y);
+                const RaySetup rs = setup_ray<STRICT>(T, lutLds, s1.x, s1.y);
             o0x = rs.o0x; o0y = rs.o0y; maxScale = rs.maxScale; translation = rs.translation; sn = rs.sn; cs = rs.cs;
             lutMiss = rs.flags; dead = rs.dead;
             if constexpr (GUARD) unsure = active && T.useLUT && rs.lutEdge;
+                ZOIC_MARK(1)   // setup_ray
             tries = 0;
             o = V3{o0x, o0y, T.originShift};
             searching = GUARD ? (active && !unsure) : active;
@@ -377,6 +382,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                     else if (DEAD && (lutMiss & kRetryDeadBit) != 0u) { toFinish = true; searching = false; }   // no retry can succeed
                 }
             }
+                ZOIC_MARK(2)   // first try: sampler finish, direction, interface 0
         } else {
             const uint32_t cnt = poolCnt < 64u ? poolCnt : 64u;
             poolCnt -= cnt;
@@ -408,6 +414,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             searching = active;
         }
 
+        if (fromPool) ZOIC_MARK(3)   // pool pop
         // ---- candidate search: RETRIES draw lens samples until one clears the rear element's housing (zoic.cpp:1927-1947) ----
         // Most rejected tries die at interface 0 (94 % of TESSAR retries, 91 % of wide-open PETZVAL retries, half of DOUBLE_GAUSS
         // retries); testing it alone costs a tenth of a whole try, so a lane keeps drawing -- tries and the ray's retry stream
@@ -436,9 +443,11 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             }
         }
 
+        ZOIC_MARK(4)   // retry search loop
         // ---- the fresh batches move up; issued here so that the sampler's dependent load above never waits for these loads ------
         if (!fromPool) advance_batches();
 
+        ZOIC_MARK(5)   // advance batches: probe issue + sample request
         // ---- one full trace for every lane that holds a candidate -------------------------------------------------------------
         bool ok = false;
         const V3 oStart = o, dStart = d;
@@ -490,6 +499,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 }
             }
         }
+        ZOIC_MARK(6)   // trace
         if (!memoryPhasesFirst) __builtin_amdgcn_s_setprio(0);
         // a lane that ran out at interface 0 hands out the untouched (o, d) of its last sample -- the reference's partial state
         // (the predicated trace scribbles over the registers of lanes that ride along)
@@ -514,6 +524,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
                              (tries > 0 ? 1u : 0u) | (tries << 1) | ((lutMiss & 1u) << 6));
         }
+        ZOIC_MARK(7)   // finish: counters + record store
         if constexpr (GUARD) {
             const unsigned long long m = __ballot(dropU);
             if (m != 0ull) {
@@ -547,6 +558,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 poolCnt += static_cast<uint32_t>(__popcll(m));
             }
         }
+        ZOIC_MARK(8)   // hand-overs + pool push
         // ---- hand-over lists: emptied in whole batches ---------------------------------------------------------------------
         if constexpr (GUARD) {
             if (unsureCnt >= 64u) {   // one atomic reserves exactly the entries written: no holes in the work list
@@ -686,6 +698,15 @@ static int read_pass_stats(unsigned long long *acc8, int reset)   // adds this t
     if (e != hipSuccess) return static_cast<int>(e);
     for (int i = 0; i < 8; ++i) acc8[i] += v[i];
     if (reset) { const unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_passStats), z, sizeof(z)); }
+    return static_cast<int>(e);
+}
+static int read_region_cycles(unsigned long long *acc16, int reset)
+{
+    unsigned long long v[16];
+    hipError_t e = hipMemcpyFromSymbol(v, HIP_SYMBOL(g_regionCycles), sizeof(v));
+    if (e != hipSuccess) return static_cast<int>(e);
+    for (int i = 0; i < 16; ++i) acc16[i] += v[i];
+    if (reset) { const unsigned long long z[16] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_regionCycles), z, sizeof(z)); }
     return static_cast<int>(e);
 }
 #endif

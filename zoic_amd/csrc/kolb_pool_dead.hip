@@ -16,6 +16,7 @@ int launch_kolb_pool_dead(const KolbTable &table, const BokehTables &bokeh, cons
 
 #ifdef ZOIC_PASS_STATS
 int read_pass_stats_dead(unsigned long long *acc8, int reset) { return read_pass_stats(acc8, reset); }
+int read_region_cycles_dead(unsigned long long *acc16, int reset) { return read_region_cycles(acc16, reset); }
 #endif
 
 }  // namespace zoic
