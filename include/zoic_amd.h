@@ -110,6 +110,15 @@ typedef struct zoic_ray {
 /* struct cameraData (zoic.cpp:627-643) + its device tables */
 typedef struct zoic_camera zoic_camera;
 
+/* ---- environment ---------------------------------------------------------------------------
+ * The library reads three environment variables, all of them about WHERE node_update builds its tables (the tables are
+ * identical either way; tests/test_parity_gpu.py compares both builds).  None selects a CPU ray path: there is none.
+ *   ZOIC_LUT_HOST=1    exit-pupil LUT probes traced by the host loop instead of the GPU kernel
+ *   ZOIC_CDF_HOST=1    bokeh CDFs (bokehProbability) built by the host loop instead of bokeh_cdf.hip
+ *   ZOIC_CELLS_HOST=1  bokeh cell records built by the host loop instead of build_cells_kernel
+ * Kernel tuning constants are compile-time (-D, tools/build_variant.sh): ZOIC_MIN_SEARCHING, ZOIC_CHUNK_RAYS, ZOIC_GRID_BLOCKS,
+ * ZOIC_GUARD_SCALE, ZOIC_RETRY_DEAD_MIN_SHARE, ZOIC_POOL_SLIM, ZOIC_TRACE_PREFETCH. */
+
 /* ---- library ------------------------------------------------------------------------------- */
 int         zoic_abi_version(void);
 const char *zoic_status_string(zoic_status);

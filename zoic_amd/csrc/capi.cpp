@@ -124,7 +124,7 @@ struct LaunchSlot {
     hipEvent_t done = nullptr;
     bool recorded = false;
     hipStream_t lastStream = nullptr;   // a launch on the same stream is ordered behind the previous one: no event wait needed
-    DeviceBuffer<uint32_t> redo;        // the Kolb launch's scratch (kolb_scratch_dwords): work list of decision-safe FAST, finish kernel's byte map
+    DeviceBuffer<uint32_t> redo;        // the Kolb launch's scratch (kolb_scratch_dwords): work list of decision-safe FAST
 };
 
 // Private scratch of ONE host-buffer call in flight: leased from the camera's pool for the duration of the call.
@@ -575,7 +575,8 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
         lk = std::unique_lock<std::mutex>(slot->m);
     }
     (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error of this call
-    if (slot->recorded && slot->lastStream != stream) ZOIC_HIP(hipStreamWaitEvent(stream, slot->done, 0));
+    // always through the event (free on the stream that recorded it): a stream handle can be destroyed and its address reused
+    if (slot->recorded) ZOIC_HIP(hipStreamWaitEvent(stream, slot->done, 0));
     if (needList && slot->redo.cap < listEntries) {
         // growing the scratch frees the old one: the slot's previous launch must be over (rare: first use / a larger batch)
         if (slot->recorded) ZOIC_HIP(hipEventSynchronize(slot->done));
@@ -587,19 +588,19 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
                               needList ? slot->redo.ptr : nullptr, stream);
     else
         rc = launch_thin_rays(cam->thin, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, mode != 0, stream);
+    // whatever the launcher returned, part of the launch (cursor reset, the first kernel) may be queued: the slot's next user
+    // must wait behind it
+    const hipError_t re = hipEventRecord(slot->done, stream);
+    if (re == hipSuccess) { slot->recorded = true; slot->lastStream = stream; }
     if (rc != 0) return fail(ZOIC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-    ZOIC_HIP(hipEventRecord(slot->done, stream));
-    slot->recorded = true;
-    slot->lastStream = stream;
+    ZOIC_HIP(re);
     return ZOIC_OK;
 }
 
 // samples per piece of the host-buffer pipeline: about eight pieces per call, 256 Ki ... 4 Mi samples each
-// (a piece must amortise a launch's fixed cost and still leave something to overlap); ZOIC_HOST_PIECE overrides
+// (a piece must amortise a launch's fixed cost and still leave something to overlap)
 uint64_t host_piece(uint64_t n)
 {
-    static const uint64_t forced = [] { const char *e = std::getenv("ZOIC_HOST_PIECE"); return e ? static_cast<uint64_t>(std::atoll(e)) : 0ull; }();
-    if (forced) return forced;
     uint64_t p = ((n + 7) / 8 + 65535) / 65536 * 65536;
     if (p < (256ull << 10)) p = 256ull << 10;
     if (p > (4ull << 20)) p = 4ull << 20;

@@ -231,8 +231,8 @@ void LensSystem::fill_surfaces(KolbTable &t) const
     // eps*|R|/r_stop (1e-4 ... 5e-3, relative) of the edge.  Measured (tools/flip_analysis.py, 8.4 M rays per config): every
     // FAST/STRICT disagreement but ~1e-7 of the rays is decided at the stop, with relative margins up to 0.9 x eps*|R|/r_stop.
     // An interface is guarded when that estimate exceeds kGuardMinRelBand (well-conditioned interfaces sit at ~1e-6 and
-    // disagree on < 1e-6 of the rays); its band is kGuardScale times the estimate.  ZOIC_GUARD_SCALE overrides (experiments).
-    static const float guardScale = [] { const char *e = std::getenv("ZOIC_GUARD_SCALE"); return e ? static_cast<float>(std::atof(e)) : kGuardScale; }();
+    // disagree on < 1e-6 of the rays); its band is kGuardScale times the estimate.  (compile with -DZOIC_GUARD_SCALE=x for experiments).
+    const float guardScale = kGuardScale;
     const float eps = 5.9604645e-8f;
     t.bandLutBin = 16.0f * eps * 32.0f;   // dist*8 <= 31: a few ulps of the bin coordinate
     for (int i = 0; i < n; ++i) {
@@ -400,8 +400,7 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
     // n.d < 0 resp. > 0 against the sign of n.z -- possible only for |d.xy| / dirZ > sqrt(R^2 - a^2) / a.  retryMaxD is that
     // bound on |d.xy| (1 % margin); the per-ray test leaves rays that could exceed it to their 26 draws.
     t.retryOn = 0; t.retryK1 = t.retryRho0 = t.retrySpread = t.retryMaxD = 0.0f;
-    static const bool retryOff = [] { const char *e = std::getenv("ZOIC_RETRY_DEAD"); return e && e[0] == '0'; }();   // A/B: no ray is ever classified
-    if (hasLUT && !rows.empty() && !retryOff) {
+    if (hasLUT && !rows.empty() && kRetryDeadMinShare < 1.0) {
         const double R = rows[0].radius, a = std::sqrt(static_cast<double>(t.surf[0].housing2)), dirZ = t.dirZ, oz = originShift;
         if (a < std::fabs(R) && dirZ > 0.0) {
             const double sag = std::fabs(R) - std::sqrt(R * R - a * a);
@@ -436,8 +435,7 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
                 const float dxyMax = std::fabs(maxScale) * 1.4158f + std::fabs(translation) * 1.4158f + dist;
                 if (ccx * ccx + ccy * ccy > reach * reach && dxyMax <= t.retryMaxD) ++hits;
             }
-        static const double minShare = [] { const char *e = std::getenv("ZOIC_RETRY_DEAD_MIN_SHARE"); return e ? std::atof(e) : 0.02; }();
-        if (hits < minShare * grid * grid) t.retryOn = 0;
+        if (hits < kRetryDeadMinShare * grid * grid) t.retryOn = 0;
     }
 }
 

@@ -28,7 +28,16 @@ struct LensRow {
 
 // decision-safe FAST mode (lens_system.cpp fill_surfaces): interfaces whose rounding-noise estimate eps*|R|/sqrt(housing2)
 // exceeds kGuardMinRelBand are guarded with a band of kGuardScale x the estimate
-constexpr float kGuardScale = 2.0f;
+#ifndef ZOIC_GUARD_SCALE
+#define ZOIC_GUARD_SCALE 2.0f   // experiments: -DZOIC_GUARD_SCALE=x (0: no ray is ever listed)
+#endif
+constexpr float kGuardScale = ZOIC_GUARD_SCALE;
+// share of the sensor square the retry-dead test must classify for the in-kernel completion of such rays to be compiled in
+// (fill_table; 0: for every camera with a LUT, >= 1: never -- experiments: -DZOIC_RETRY_DEAD_MIN_SHARE=x)
+#ifndef ZOIC_RETRY_DEAD_MIN_SHARE
+#define ZOIC_RETRY_DEAD_MIN_SHARE 0.02
+#endif
+constexpr double kRetryDeadMinShare = ZOIC_RETRY_DEAD_MIN_SHARE;
 constexpr float kGuardMinRelBand = 2.0e-5f;
 
 struct LutBox { float maxX = 0, maxY = 0, minX = 0, minY = 0; };  // boundingBox2d, zoic.cpp:490-493

@@ -14,6 +14,13 @@
 
 #include "kernels.hpp"
 
+#ifndef ZOIC_CHUNK_RAYS
+#define ZOIC_CHUNK_RAYS 0u
+#endif
+#ifndef ZOIC_GRID_BLOCKS
+#define ZOIC_GRID_BLOCKS 0ull
+#endif
+
 namespace zoic {
 
 constexpr uint32_t kMaxChunkRays = 1024;   // 16 passes of fresh work
@@ -24,12 +31,12 @@ struct WorkGrain { uint32_t chunkRays, chunksPerPart; };
 // changes chunk -- an exposed atomic + window fetch -- every few passes otherwise): 512 for the FAST Kolb kernels (TESSAR
 // 1080p x 8, 16.6 M rays: 256 -> 21.5, 384 -> 22.4, 512 -> 23.1, 768 -> 21.9, 1024 -> 21.0 Grays/s unchecked), 256 for the
 // STRICT ones, whose passes are 2.5x longer (14.9 at 256, 14.5 at 512) and for the thin lens; 512 on a 4K x 16spp frame by
-// the claim budget, 1024 at most.  ZOIC_CHUNK_RAYS overrides the rule (experiments).
+// the claim budget, 1024 at most.  -DZOIC_CHUNK_RAYS=n overrides the rule (experiments).
 inline WorkGrain work_grain(uint64_t m, uint32_t floorRays = 256)
 {
     uint64_t chunk = (m / (32768ull * kCursorParts) + 63) / 64 * 64;
     if (chunk < floorRays && m >= (4ull << 20)) chunk = floorRays;
-    static const uint32_t chunkOverride = [] { const char *e = std::getenv("ZOIC_CHUNK_RAYS"); return e ? static_cast<uint32_t>(std::atoi(e)) : 0u; }();
+    constexpr uint32_t chunkOverride = ZOIC_CHUNK_RAYS;
     WorkGrain g;
     g.chunkRays = chunkOverride ? chunkOverride : static_cast<uint32_t>(chunk < 64 ? 64 : (chunk > kMaxChunkRays ? kMaxChunkRays : chunk));
     const uint64_t totalChunks = (m + g.chunkRays - 1) / g.chunkRays;
@@ -49,12 +56,12 @@ inline hipError_t reset_work_cursors(unsigned int *d_workCursor, hipStream_t st)
 // chip runs short of waves to hide latency with.  Measured optimum on TESSAR unchecked / double Gauss decision-safe /
 // TESSAR strict alike (tools/exp_grid.py): 256 K rays -> 256 workgroups, 1 M -> 512, 4 M -> 1024, 16 M -> 2048; against
 // "one wave per 64 rays, 2048 at most": 1 M rays 293 -> 167 us, 2 M 337 -> 235, 4 M 303 -> 272 (TESSAR unchecked).
-// ZOIC_GRID_BLOCKS overrides the rule (experiments).
+// -DZOIC_GRID_BLOCKS=n overrides the rule (experiments).
 inline unsigned persistent_grid(uint64_t m, unsigned wavesPerBlock)
 {
     const uint64_t tiles = (m + 63) / 64;
     const uint64_t wantBlocks = (tiles + wavesPerBlock - 1) / wavesPerBlock;
-    static const uint64_t capOverride = [] { const char *e = std::getenv("ZOIC_GRID_BLOCKS"); return e ? static_cast<uint64_t>(std::atol(e)) : uint64_t(0); }();
+    constexpr uint64_t capOverride = ZOIC_GRID_BLOCKS;
     uint64_t cap = 2048;
     if (capOverride) cap = capOverride;
     else {
