@@ -56,9 +56,11 @@ typedef enum zoic_lens_model { ZOIC_THINLENS = 0, ZOIC_RAYTRACED = 1, ZOIC_LENS_
 typedef enum zoic_precision {
     ZOIC_PRECISION_STRICT = 0, /* the reference's operation order, no FMA contraction, its f64 intermediates: bit-exact vs the CPU oracle */
     ZOIC_PRECISION_FAST = 1,   /* same algorithm, f32 only, FMA/rsq, redundant normalisations removed: direction RMSE < 1e-5.
-                                  Decision-safe: every accept/reject decision too close to call in this arithmetic is re-taken
-                                  in STRICT arithmetic (a second kernel over the few rays concerned), so try counts, weights,
-                                  flags and counters are the reference's; only low-order bits of origin/direction differ */
+                                  Decision-safe: accept/reject decisions at ill-conditioned interfaces (in practice the stop, which
+                                  the reference traces as a sphere of |R| ~ 1e4 cm) that lie inside their guard band, and the
+                                  exit-pupil LUT's edge, are re-taken in STRICT arithmetic (a second kernel over the few rays
+                                  concerned).  Sphere-miss, TIR and well-conditioned clips are not guarded: residual flips of try
+                                  count / weight <= ~1e-6 of the rays (tests hold 5e-5); origin / direction differ in low-order bits */
     ZOIC_PRECISION_FAST_UNCHECKED = 2 /* FAST without the decision check (A/B; decisions flip where the reference's own f32
                                          rounding noise decides, ~1e-5 ... 1e-3 of the rays depending on the lens) */
 } zoic_precision;
@@ -158,7 +160,7 @@ zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed);
  * (zoic.cpp:648); a per-ray stream is the only order-independent restatement. */
 zoic_status zoic_create_rays_device(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng_states,
                                     uint64_t ray_index_base, zoic_ray *d_rays, void *stream);
-/* same, host buffers: H2D, kernels, D2H in pieces on two private streams; returns when h_rays is complete */
+/* same, host buffers: H2D, kernels, D2H in pieces on three private streams (copy-in, kernels, copy-out); returns when h_rays is complete */
 zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_samples, const uint32_t *h_rng_states,
                                   uint64_t ray_index_base, zoic_ray *h_rays);
 /* Arnold-layout batch: n AtCameraInput -> n AtCameraOutput (host arrays; page-locked ones -- zoic_host_alloc /
@@ -169,11 +171,12 @@ zoic_status zoic_create_rays_host(zoic_camera *cam, uint64_t n, const float *h_s
  * taken as 0, as Arnold hands it in.  Ray i draws its retries from the stream keyed by ray_index_base + i. */
 zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_camera_input *inputs,
                                     zoic_camera_output *outputs, uint64_t ray_index_base);
-/* camera_create_ray(node, input, output, tid), zoic.cpp:1752: the per-sample signature (latency bound: one launch
- * per sample, sample and ray cross PCIe through mapped pinned memory).  Re-entrant: every tid owns a retry stream
- * that carries over from call to call, so two samples that retry never see the same draws; tid 0's stream is the
- * reference's process-global xor128 state (seeded 123456789..., advanced by node_update's LUT build and by every
- * retry), so ONE render thread reproduces the reference's sequential output exactly (STRICT precision). */
+/* camera_create_ray(node, input, output, tid), zoic.cpp:1752: the per-sample signature.  No launch per call: the sample goes
+ * to a resident kernel through mapped pinned memory (csrc/mailbox.hip; ~7 us per call; the kernel retires by itself after 1 ms
+ * without a call and is started again by the next one).  Re-entrant: every tid owns a retry stream that carries over from call
+ * to call, so two samples that retry never see the same draws; tid 0's stream is the reference's process-global xor128 state
+ * (seeded 123456789..., advanced by node_update's LUT build and by every retry), so ONE render thread reproduces the
+ * reference's sequential output exactly (STRICT precision). */
 zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output,
                                    uint16_t tid);
 /* camera_reverse_ray, zoic.cpp:1992-1995: the reference returns false and writes nothing; so does this (returns 0). */
