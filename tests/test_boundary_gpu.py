@@ -61,6 +61,47 @@ def test_one_render_thread_replays_the_reference_process(gpu, oracle_lib):
     assert np.array_equal(bits(got2[:, 3:6].T.copy()), bits(ref2["dir"]))
 
 
+def test_mailbox_survives_idle_lifetime_mode_changes_and_shared_slots(gpu, oracle_lib):
+    """The resident per-sample kernel (csrc/mailbox.hip) retires after 1 ms without a call and after 50 ms in any case, is
+    stopped by set_precision / update / the counter getters, and serves tids 64 apart from ONE slot.  Whatever it does, the
+    rays of a tid are those of that tid's retry stream: tid 0 = the oracle's sequential run (a fresh camera per leg), the
+    other tids = a per-tid replay on a second camera that is never disturbed."""
+    import time
+    from zoic_amd import PRECISION_FAST
+    oc = oracle_lib.OracleCamera()
+    oc.update(**camera_params("C2"))
+    s, _ = _slab("C2", 8 * 700, 0.2)
+    s = s[::8]
+    ref = oc.create_rays(s)                                    # tid 0: the sequential global stream
+    cam = _c2_camera()
+    got = []
+    for k, row in enumerate(s):
+        if k in (50, 120, 121, 400):
+            time.sleep(0.02)                                   # > 1 ms idle: the kernel has retired, the call restarts it
+        if k == 200:
+            cam.set_precision(PRECISION_FAST)                  # stops the kernel; STRICT again before the next call
+            cam.set_precision(PRECISION_STRICT)
+        if k == 300:
+            assert cam.counters()["succesRays"] + cam.counters()["vignettedRays"] == 300   # stops it, its counts arrive
+        got.append(_out_tuple(cam.create_ray(*[float(v) for v in row], tid=0)))
+    got = np.array(got, np.float32)
+    assert np.array_equal(bits(got[:, 3:6].T.copy()), bits(ref["dir"])) and np.array_equal(got[:, 6], ref["weight"])
+    # > 50 ms of uninterrupted calls (the lifetime cap restarts the kernel in mid-flight), three tids on one slot
+    plain = _c2_camera()
+    tids = (3, 67, 131, 3, 131, 67)
+    rows = [[float(v) for v in s[(7 * i) % len(s)]] for i in range(6000)]
+    a = [_out_tuple(cam.create_ray(*rows[i], tid=tids[i % 6])) for i in range(6000)]
+    want = {}
+    for t in (3, 67, 131):                                     # the same calls, one tid after the other, on an undisturbed camera
+        for i in range(6000):
+            if tids[i % 6] == t:
+                want[i] = _out_tuple(plain.create_ray(*rows[i], tid=t))
+    assert all(a[i] == want[i] for i in range(6000))
+    total = cam.counters()
+    assert total["succesRays"] + total["vignettedRays"] == 700 + 6000
+    cam.close(); plain.close()
+
+
 def test_two_per_sample_calls_that_retry_draw_different_numbers(gpu):
     """Round 1 keyed every per-sample call to ray index 0: all retried samples of a frame drew the same (u, v) sequence.
     Now the tid's stream carries over, so the same sample submitted twice retries with different draws."""

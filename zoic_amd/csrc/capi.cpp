@@ -1085,11 +1085,16 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
     q->seq2 = seq; q->seq1 = seq; q->seq0 = seq;
     // reply: complete when its three chunks carry this call's number
     volatile MailReply *a = M.reply(slot);
-    for (uint32_t spins = 1;; ++spins) {
+    for (uint64_t spins = 1;; ++spins) {
         if (a->seq0 == seq && a->seq1 == seq && a->seq2 == seq) break;
         __builtin_ia32_pause();
-        if ((spins & 2047u) == 0u && M.header()->alive == 0u) {   // the kernel retired (idle / lifetime) around this call: start it again
+        if ((spins & 2047u) != 0u) continue;
+        if (M.header()->alive == 0u) {   // the kernel retired (idle / lifetime) around this call: start it again
             if (zoic_status s = mailbox_ensure_running(cam, slot)) return s;
+        } else if ((spins & 0xfffffu) == 0u) {
+            // every ~20 ms: a kernel that died (fault) never clears `alive` -- ask the stream; and never wait for ever
+            if (zoic_status s = mailbox_ensure_running(cam, slot)) return s;
+            if (spins > (1ull << 30)) return fail(ZOIC_ERR_HIP, "per-sample kernel did not answer");
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
