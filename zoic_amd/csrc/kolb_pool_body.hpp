@@ -357,12 +357,14 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             const float u = s1.z, v = s1.w;
             // dead pixel (outside the image circle, LUT entries zero): whatever finite point the sampler returns, the direction
             // is (0 - o.x, 0 - o.y, dirZ); samples in [0,1)^2 off the disk mapping's 0/0 centre need no sampler
-            const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
             V2 lens;
             if constexpr (PROBE) lens = bokeh_cells_finish<STRICT>(B, T.bokehW, T.bokehH, v, probe);
             else lens = sample_lens(u, v);
-            if (dead && plainSample) lens = V2{0.0f, 0.0f};
-            finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
+            if (__ballot(dead) != 0ull) {   // wave-uniform: most waves hold no dead pixel and skip these dozen compares
+                const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
+                if (dead && plainSample) lens = V2{0.0f, 0.0f};
+                finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
+            }
             if (!T.useLUT) {                    // zoic.cpp:1873-1877
                 d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
             } else {                            // zoic.cpp:1913-1924: the first sample is translated in x only
@@ -553,8 +555,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
 #else
                     pool1[slot] = make_float4(maxScale, translation, sn, cs);
 #endif
-                    pool2[slot] = make_uint4(rng.x, rng.y, rng.z, rng.w);
                 }
+                // the retry stream of a ray that has not drawn yet is seeded when it is popped (tries == 0): nothing to store
+                if (__ballot(keep && tries != 0u) != 0ull) { if (keep) pool2[poolCnt + mask_rank(m)] = make_uint4(rng.x, rng.y, rng.z, rng.w); }
                 poolCnt += static_cast<uint32_t>(__popcll(m));
             }
         }
