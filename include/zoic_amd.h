@@ -115,7 +115,8 @@ typedef struct zoic_camera zoic_camera;
 /* ---- environment ---------------------------------------------------------------------------
  * The library reads three environment variables, all of them about WHERE node_update builds its tables (the tables are
  * identical either way; tests/test_parity_gpu.py compares both builds).  None selects a CPU ray path: there is none.
- *   ZOIC_LUT_HOST=1    exit-pupil LUT probes traced by the host loop instead of the GPU kernel
+ *   ZOIC_LUT_HOST=1    exit-pupil LUT (draws, probe traces, bounding boxes) built by the host loop instead of lut_build.hip;
+ *                      =2: probes traced on the GPU, draws and the order-dependent box replay on the host (round 1's build)
  *   ZOIC_CDF_HOST=1    bokeh CDFs (bokehProbability) built by the host loop instead of bokeh_cdf.hip
  *   ZOIC_CELLS_HOST=1  bokeh cell records built by the host loop instead of build_cells_kernel
  * Kernel tuning constants are compile-time (-D, tools/build_variant.sh): ZOIC_MIN_SEARCHING, ZOIC_CHUNK_RAYS, ZOIC_GRID_BLOCKS,

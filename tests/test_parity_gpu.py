@@ -327,16 +327,34 @@ def test_full_frame_properties_other_configs(gpu, oracle_lib, cfg, frac_lo, frac
     assert frac_lo <= cnt["vignettedRays"] / n <= frac_hi
 
 
-def test_gpu_lut_build_equals_host_lut_build(gpu, oracle_lib, monkeypatch):
-    """node_update traces the 3.2 M exit-pupil probes on the GPU by default; ZOIC_LUT_HOST=1 keeps them on the host.
-    Both must give the oracle's table."""
-    p = camera_params("C4")
-    a = ZoicCamera(0).update(**p).info()
-    monkeypatch.setenv("ZOIC_LUT_HOST", "1")
-    b = ZoicCamera(0).update(**p).info()
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
+def test_gpu_lut_build_equals_host_lut_build(gpu, oracle_lib, monkeypatch, cfg):
+    """node_update builds the exit-pupil LUT on the GPU by default -- every thread jumps into the reference's ONE sequential
+    xorshift128 stream (GF(2) matrix powers), draws, traces and boxes its probes (lut_build.hip); ZOIC_LUT_HOST=2 is round 1's
+    build (GPU traces, host draws and replay), =1 the host loop.  All three must give the oracle's table, its TIR count and
+    leave the stream where the reference leaves it (the next retry of tid 0 draws from there)."""
+    p = dict(camera_params(cfg), useImage=False)
     oc = oracle_lib.OracleCamera().update(**p)
-    assert np.array_equal(bits(a["lutBoxes"]), bits(b["lutBoxes"]))
-    assert np.array_equal(bits(a["lutBoxes"]), bits(oc.lut()[1]))
+    n = 2000
+    s, _ = slab(cfg, 8 * n, 0.3)
+    s = s[::8]
+    ref = oc.create_rays(s)                                  # the sequential global stream, continuing after the LUT build
+    for mode in (None, "2", "1"):
+        if mode is None:
+            monkeypatch.delenv("ZOIC_LUT_HOST", raising=False)
+        else:
+            monkeypatch.setenv("ZOIC_LUT_HOST", mode)
+        cam = ZoicCamera(0).update(**p)
+        assert np.array_equal(bits(cam.info()["lutBoxes"]), bits(oc.lut()[1])), mode
+        assert cam.counters()["totalInternalReflection"] == oc_tir_after_update(oracle_lib, p), mode
+        got = [cam.create_ray(*[float(v) for v in row], tid=0) for row in s[:400]]
+        d = np.array([(o.dir.x, o.dir.y, o.dir.z) for o in got], np.float32)
+        assert np.array_equal(bits(d.T.copy()), bits(ref["dir"][:, :400])), mode
+        cam.close()
+
+
+def oc_tir_after_update(oracle_lib, p):
+    return oracle_lib.OracleCamera().update(**p).counters()["totalInternalReflection"]
 
 
 @pytest.mark.parametrize("shape,kind", [((256, 256), "hexagon"), ((200, 300), "random"), ((37, 5), "random"), ((6, 4), "flat"),

@@ -13,12 +13,14 @@ def t(f, n=3):
 
 for cfg in ("C2", "C4", "C5"):
     p = camera_params(cfg)
+    res = []
+    for mode in (None, "2", "1"):
+        os.environ.pop("ZOIC_LUT_HOST", None)
+        if mode:
+            os.environ["ZOIC_LUT_HOST"] = mode
+        res.append(t(lambda: ZoicCamera(0).update(**p)))
     os.environ.pop("ZOIC_LUT_HOST", None)
-    g = t(lambda: ZoicCamera(0).update(**p))
-    os.environ["ZOIC_LUT_HOST"] = "1"
-    h = t(lambda: ZoicCamera(0).update(**p))
-    os.environ.pop("ZOIC_LUT_HOST", None)
-    print("%s node_update: GPU LUT probes %.1f ms, host LUT %.1f ms" % (cfg, g, h))
+    print("%s node_update: LUT on the GPU %.1f ms, GPU traces + host draws/replay %.1f ms, host %.1f ms" % ((cfg,) + tuple(res)))
 for size in (256, 1024, 2048, 4096):
     img = hexagon_bokeh(size)
     def run():

@@ -237,7 +237,7 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     zoic_precision precision = ZOIC_PRECISION_STRICT;
     uint32_t seed = 1;
     bool updated = false;
-    bool lutOnHost = false;
+    bool lutOnHost = false, lutHostDraws = false;
     // pending inputs; the dirty flags force the rebuild on the next update even under an unchanged path
     std::vector<float> pendingPixels; int pendW = 0, pendH = 0, pendC = 0;
     std::string lensText; bool haveLensText = false;
@@ -362,6 +362,12 @@ void lut_trace_device(const KolbTable &table, float originX, const float *lensU,
         return;
     }
     *tirCount += tir;
+}
+
+// LutBuildFn: the whole exit-pupil LUT on the GPU (lut_build.hip)
+int lut_build_whole_device(const KolbTable &table, Rng &rng, LutBox boxes[kLutEntries], uint32_t *tirCount, void *)
+{
+    return build_lut_device(table, rng, boxes, tirCount);
 }
 
 // one padded pyramid: level 0 = the CDF, level j+1 = last element of each 16-chunk of level j (tables.hpp)
@@ -683,8 +689,9 @@ zoic_status zoic_camera_create(int device, zoic_camera **out)
     std::unique_ptr<zoic_camera> cam(new zoic_camera());
     cam->device = device;
     rng_seed_reference(cam->stream);
-    const char *env = std::getenv("ZOIC_LUT_HOST");
+    const char *env = std::getenv("ZOIC_LUT_HOST");   // 1: draws, traces and boxes on the host; 2: GPU traces, host draws + replay (round 1's build)
     cam->lutOnHost = env && env[0] == '1';
+    cam->lutHostDraws = env && env[0] == '2';
     cam->tidStates.reset(new std::atomic<TidState *>[kTidStates]);
     for (unsigned i = 0; i < kTidStates; ++i) cam->tidStates[i].store(nullptr, std::memory_order_relaxed);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&cam->dCounters), kCounterSets * sizeof(DeviceCounters));   // kernels.hpp: one set per line
@@ -848,7 +855,8 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
             if (zoic_status s = lens_error_status(cam->lens.parse(text.data(), text.size()))) return s;
             g_lastError.clear();
             LensError le = cam->lens.prepare(p->focalLength, p->fStop, p->focalDistance, p->kolbSamplingLUT != 0, cam->stream,
-                                             cam->lutOnHost ? lut_trace_host : lut_trace_device, cam);
+                                             cam->lutOnHost ? lut_trace_host : lut_trace_device, cam,
+                                             (cam->lutOnHost || cam->lutHostDraws) ? nullptr : lut_build_whole_device);
             if (zoic_status s = lens_error_status(le)) return s;
             if (!g_lastError.empty()) return ZOIC_ERR_HIP;
             // counters restart with the lens (zoic.cpp:1626-1628); the precompute's TIR bumps stay in (zoic.cpp:1135 ff.)

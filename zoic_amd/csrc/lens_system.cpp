@@ -273,7 +273,7 @@ void LensSystem::fill_surfaces(KolbTable &t) const
 }
 
 LensError LensSystem::prepare(float focalLength, float fStop, float focalDistance, bool useLUT, Rng &rng, LutTraceFn trace,
-                              void *traceUser)
+                              void *traceUser, LutBuildFn whole)
 {
     const int n = static_cast<int>(rows.size());
     precomputeTIR = 0;
@@ -322,7 +322,7 @@ LensError LensSystem::prepare(float focalLength, float fStop, float focalDistanc
         summed = (i == 0) ? rows[0].thickness : summed + rows[i].thickness;
         rows[i].center = summed - rows[i].radius;
     }
-    if (useLUT) build_lut(rng, trace ? trace : lut_trace_host, traceUser);
+    if (useLUT) build_lut(rng, trace ? trace : lut_trace_host, traceUser, whole);
     return LensError::None;
 }
 
@@ -342,13 +342,22 @@ void lut_trace_host(const KolbTable &table, float originX, const float *lensU, c
 // exitPupilLUT(&ld, 32, 100000), zoic.cpp:1391-1452.  Every probe consumes exactly two draws whatever its fate
 // (zoic.cpp:1411-1412), so the sample set is a pure function of the stream position: draw all of them, trace
 // them as one batch (host, or the GPU kernel), then replay the order-dependent bounding-box update.
-void LensSystem::build_lut(Rng &rng, LutTraceFn trace, void *user)
+void LensSystem::build_lut(Rng &rng, LutTraceFn trace, void *user, LutBuildFn whole)
 {
     constexpr int kFilmSamples = kLutEntries;
     constexpr int kBoundsSamples = 100000;
     KolbTable t{};
     fill_surfaces(t);
     const float spacing = 4.0f / static_cast<float>(kFilmSamples);
+    if (whole) {   // draws, traces and boxes on the GPU (lut_build.hip); anything but 0: the sequential path below
+        uint32_t tir = 0;
+        if (whole(t, rng, lutBox, &tir, user) == 0) {
+            for (int i = 0; i < kFilmSamples; ++i) lutKey[i] = static_cast<float>(spacing * static_cast<float>(i));
+            precomputeTIR += tir;
+            hasLUT = true;
+            return;
+        }
+    }
     const float ap0 = rows[0].aperture;
     std::vector<float> U(kBoundsSamples), V(kBoundsSamples);
     std::vector<uint8_t> ok(kBoundsSamples);

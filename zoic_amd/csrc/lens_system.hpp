@@ -40,12 +40,18 @@ constexpr float kGuardScale = ZOIC_GUARD_SCALE;
 constexpr double kRetryDeadMinShare = ZOIC_RETRY_DEAD_MIN_SHARE;
 constexpr float kGuardMinRelBand = 2.0e-5f;
 
+
 struct LutBox { float maxX = 0, maxY = 0, minX = 0, minY = 0; };  // boundingBox2d, zoic.cpp:490-493
 
 // Accept/reject of one batch of exit-pupil probe rays.  The default implementation traces on the host;
 // the GPU build swaps in a kernel launch (same strict arithmetic) -- see capi.cpp.
 using LutTraceFn = void (*)(const KolbTable &table, float originX, const float *lensU, const float *lensV, size_t n,
                             uint8_t *accepted, uint32_t *tirCount, void *user);
+
+// The whole exit-pupil LUT in one go (lut_build.hip: draws, traces and boxes on the GPU).  Returns 0 when `boxes`, `*tirCount`
+// and the advanced `rng` are the reference's; anything else leaves them untouched and the per-entry path below runs.
+using LutBuildFn = int (*)(const KolbTable &table, Rng &rng, LutBox boxes[kLutEntries], uint32_t *tirCount, void *user);
+int build_lut_device(const KolbTable &table, Rng &rng, LutBox boxes[kLutEntries], uint32_t *tirCount);
 
 class LensSystem {
 public:
@@ -54,7 +60,7 @@ public:
     // cleanupLensData .. computeLensCenters (+ exitPupilLUT when useLUT), zoic.cpp:1648-1692.
     // `rng` is the process-wide xorshift128 stream the LUT build draws from (zoic.cpp:1411-1412).
     LensError prepare(float focalLength, float fStop, float focalDistance, bool useLUT, Rng &rng,
-                      LutTraceFn trace = nullptr, void *traceUser = nullptr);
+                      LutTraceFn trace = nullptr, void *traceUser = nullptr, LutBuildFn whole = nullptr);
     // flatten for the kernels
     void fill_table(KolbTable &t, float sensorWidth) const;
 
@@ -70,7 +76,7 @@ public:
 private:
     float trace_focal_length();                       // traceThroughLensElementsForFocalLength, zoic.cpp:1161-1228
     float image_distance(float objectDistance);       // calculateImageDistance, zoic.cpp:1054-1095
-    void build_lut(Rng &rng, LutTraceFn trace, void *user);  // exitPupilLUT, zoic.cpp:1391-1452
+    void build_lut(Rng &rng, LutTraceFn trace, void *user, LutBuildFn whole);  // exitPupilLUT, zoic.cpp:1391-1452
     void fill_surfaces(KolbTable &t) const;
 };
 
