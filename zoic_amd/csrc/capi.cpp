@@ -120,7 +120,9 @@ public:
 // launches are in flight -- with up to kLaunchSlots of them no launch waits at all.
 struct LaunchSlot {
     std::mutex m;                 // held only while a launch is being enqueued
-    unsigned int *cursor = nullptr;
+    unsigned int *cursor = nullptr;     // TWO cursor blocks: a Kolb launch works on block `parity` and clears the other (kernels.hpp)
+    unsigned parity = 0;
+    bool cursorsDirty = false;          // a thin-lens launch or a failed launch left a block non-zero: memset both before the next Kolb launch
     hipEvent_t done = nullptr;
     bool recorded = false;
     hipStream_t lastStream = nullptr;   // a launch on the same stream is ordered behind the previous one: no event wait needed
@@ -589,11 +591,18 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
         ZOIC_HIP(slot->redo.reserve(listEntries));
     }
     int rc;
-    if (model == ZOIC_RAYTRACED)
-        rc = launch_kolb_rays(cam->kolb, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, mode,
+    if (model == ZOIC_RAYTRACED) {
+        if (slot->cursorsDirty) {
+            ZOIC_HIP(hipMemsetAsync(slot->cursor, 0, 2 * kCursorStride * sizeof(unsigned int), stream));
+            slot->cursorsDirty = false;
+        }
+        rc = launch_kolb_rays(cam->kolb, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, &slot->parity, mode,
                               needList ? slot->redo.ptr : nullptr, stream);
-    else
+        if (rc != 0) slot->cursorsDirty = true;
+    } else {
         rc = launch_thin_rays(cam->thin, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, mode != 0, stream);
+        slot->cursorsDirty = true;   // the thin-lens kernels reset the block they use themselves and leave it used
+    }
     // whatever the launcher returned, part of the launch (cursor reset, the first kernel) may be queued: the slot's next user
     // must wait behind it
     const hipError_t re = hipEventRecord(slot->done, stream);
@@ -696,9 +705,10 @@ zoic_status zoic_camera_create(int device, zoic_camera **out)
     for (unsigned i = 0; i < kTidStates; ++i) cam->tidStates[i].store(nullptr, std::memory_order_relaxed);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&cam->dCounters), kCounterSets * sizeof(DeviceCounters));   // kernels.hpp: one set per line
     if (e == hipSuccess) e = hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), kLaunchSlots * kCursorStride * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cam->dWorkCursor), kLaunchSlots * 2 * kCursorStride * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(cam->dWorkCursor, 0, kLaunchSlots * 2 * kCursorStride * sizeof(unsigned int));
     for (unsigned i = 0; e == hipSuccess && i < kLaunchSlots; ++i) {
-        cam->slots[i].cursor = cam->dWorkCursor + i * kCursorStride;
+        cam->slots[i].cursor = cam->dWorkCursor + i * 2 * kCursorStride;
         e = hipEventCreateWithFlags(&cam->slots[i].done, hipEventDisableTiming);
     }
     if (e != hipSuccess) {

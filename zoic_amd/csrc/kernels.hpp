@@ -59,8 +59,12 @@ inline size_t kolb_scratch_dwords(const KolbTable &, uint64_t n, int mode)
 {
     return mode == 1 ? static_cast<size_t>(n < (1ull << 31) ? n : (1ull << 31)) : 0;
 }
+// d_cursorPair: TWO cursor blocks (2 x kCursorBlockWords dwords, zero when the camera is created); a launch works on block
+// *parity and its first workgroup clears the other one for the launch after it (which the slot's event chain orders behind
+// this one) -- no memset node per launch.  *parity is flipped per kernel pipeline launched.
+constexpr unsigned kCursorBlockWords = kCursorParts * kCursorPartStride;
 int launch_kolb_rays(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                     uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_cursorPair, unsigned *parity,
                      int mode, uint32_t *d_scratch, void *stream);
 
 // camera_create_ray, THINLENS branch (zoic.cpp:1771-1846).  With optical vignetting on (retries possible) the

@@ -50,6 +50,7 @@ struct KolbKernelArgs {
     KolbTable T; BokehTables B; const float4 *samples; const uint4 *rngStates; uint64_t rayBase; uint32_t n; RayRecord *out;
     DeviceCounters *counters; unsigned int *workCursor; uint32_t ldsWords, chunkRays, chunksPerPart, minSearching;
     uint32_t *redoList; unsigned int *redoCount;             // GUARD kernel: appends the rays it cannot decide; LISTED kernel: reads them
+    unsigned int *clearCursor;                                // the cursor block of the NEXT launch on this slot: zeroed by workgroup 0 (not LISTED)
 };
 template <class V, size_t OFFSET>
 __device__ __forceinline__ V kernarg_field()
@@ -220,6 +221,90 @@ __device__ __forceinline__ uint32_t mask_rank(unsigned long long m)   // exclusi
 }
 __device__ __forceinline__ bool mask_bit(unsigned long long m, uint32_t lane) { return ((m >> lane) & 1ull) != 0ull; }
 
+// listed_short: the STRICT evaluation of a SHORT work list (kShortList rays or fewer), four tries of a ray side by side.
+// The decision-safe launch ends with the STRICT kernel over the rays the FAST kernel could not decide; on all but the fisheye
+// that list is a few thousand rays and the kernel's time is not work but ONE ray's chain of sequential tries (up to 27 passes
+// of ~5 us at one wave per SIMD: 80 us of a 570 us TESSAR frame, 80 us on top of a 110 us 1 M-ray bucket).  The tries of a ray
+// are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1), so lanes 4g .. 4g+3 of a wave evaluate
+// tries 4r .. 4r+3 of ray g in round r -- the reference's own loop body (zoic.cpp:1870-1947: lens sample, direction, branchy
+// trace), no pool, no shortcuts -- and the first success in try order wins; TIR bumps count for the tries before it only.
+// Same device functions, same per-ray streams: the same bits as the pool path.
+constexpr uint32_t kShortList = 1u << 17;
+__device__ __forceinline__ void listed_short(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
+                                             const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 3u, g = lane >> 2;
+    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock, waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t *list = ZOIC_KARG(redoList);
+    const uint4 *states = ZOIC_KARG(rngStates);
+    const uint64_t rayBase = ZOIC_KARG(rayBase);
+    uint32_t succ = 0, vign = 0, tir = 0;   // per lane; reduced at the end
+    for (uint32_t first = waveId * 16u; first < n; first += wavesTotal * 16u) {
+        const uint32_t li = first + g;
+        const bool have = li < n;
+        const uint32_t idx = list[have ? li : n - 1u];
+        const float4 s = samples[idx];
+        const RaySetup rs = setup_ray<true>(T, lutLds, s.x, s.y);
+        const V3 o0{rs.o0x, rs.o0y, T.originShift};
+        Rng rng;
+        if (states) { const uint4 q = states[idx]; rng = Rng{q.x, q.y, q.z, q.w}; }
+        else rng = rng_for_ray(T.seed, rayBase + idx);
+        for (uint32_t a = 1; a < j; ++a) { (void)xor128(rng); (void)xor128(rng); }   // lane j >= 1 starts at draw 2 (j - 1)
+        bool done = !have;
+        for (uint32_t round = 0; round < 7u; ++round) {
+            const uint32_t k = 4u * round + j;                       // this lane's try: 0 = the sample's own lens point, k = tries
+            const bool valid = !done && k <= static_cast<uint32_t>(kMaxTries) + 1u;
+            V3 o = o0, d{0.0f, 0.0f, 1.0f};
+            uint32_t tirTry = 0;
+            bool ok = false;
+            if (valid) {
+                if (k == 0u) {
+                    V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
+                    if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+                    else {                                                    // zoic.cpp:1913-1924: x-only translation
+                        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
+                        lens.x += rs.translation;
+                        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
+                        d = V3{rx - o.x, ry - o.y, T.dirZ};
+                    }
+                } else {
+                    const float u = rng_unit(xor128(rng));                    // zoic.cpp:1930
+                    const float v = rng_unit(xor128(rng));
+                    d = retry_direction(T, lens_sample<true>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+                }
+                ok = trace_lens_strict(T, o, d, tirTry);
+            }
+            // the next try of this lane, k + 4, starts at draw 2 (k + 3): six draws past where this try ended (2 k; try 0 drew nothing)
+            for (int a = 0; a < 3; ++a) { (void)xor128(rng); (void)xor128(rng); }
+            // the group's decision, in try order
+            const unsigned long long okAll = __ballot(valid && ok);
+            const uint32_t okGroup = static_cast<uint32_t>(okAll >> (4u * g)) & 15u;
+            const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : 4u;   // lowest try that got through
+            if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
+            const bool last = k == static_cast<uint32_t>(kMaxTries) + 1u;      // try 26 failed as well: weight 0, ITS partial state
+            if (valid && (j == winner || (winner == 4u && last))) {
+                // try 26 is still traced by the loop condition (zoic.cpp:1927) and hands out its state, but tries > 25 is weight 0
+                // whether it got through or not (zoic.cpp:1951-1957)
+                const bool okRay = j == winner && !last;
+                float w = okRay ? 1.0f : 0.0f;
+                if (T.exposureOn) w *= T.exposureMul;                          // zoic.cpp:1981-1987
+                store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
+                                 (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6));
+                if (okRay) ++succ; else ++vign;
+            }
+            done = done || winner != 4u || 4u * round + 3u >= static_cast<uint32_t>(kMaxTries) + 1u;
+            if (__ballot(!done) == 0ull) break;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { succ += __shfl_xor(succ, off, 64); vign += __shfl_xor(vign, off, 64); tir += __shfl_xor(tir, off, 64); }
+    DeviceCounters *counters = counter_set(ZOIC_KARG(counters));
+    if (counters && lane == 0) {
+        if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
+        if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
+        if (tir) atomicAdd(&counters->tir, static_cast<unsigned long long>(tir));
+    }
+}
+
 // IMAGE: the bokeh image is on AND its cell records are in LDS (tables.hpp; images up to 2048 rows x 4096 columns): every
 // lens sample is one ds_read_b128 + one global_load_dwordx4.  IMAGE = false covers the concentric-disk sampler and images
 // without records (16-ary pyramid / reference search through lens_sample's run-time branch).
@@ -237,11 +322,17 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         if (n == 0u) return;
         // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times over
         redoChunk = n > (1u << 20) ? 256u : 64u;
-        const uint32_t totalChunks = (n + redoChunk - 1u) / redoChunk;
+        const uint32_t totalChunks = n <= kShortList ? (n + 15u) / 16u : (n + redoChunk - 1u) / redoChunk;   // short lists: 16 rays per wave (listed_short)
         if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed for it
         redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if constexpr (!LISTED) {   // the other cursor block of this launch slot, for the launch after this one (kernels.hpp)
+        if (blockIdx.x == 0) {
+            unsigned int *next = ZOIC_KARG(clearCursor);
+            for (uint32_t i = threadIdx.x; i < kCursorBlockWords; i += kRefillBlock) next[i] = 0u;
+        }
+    }
     // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the two entries
     // a sample interpolates -- then the bokeh row cell records (tables.hpp)
     if (threadIdx.x < kLutEntries) {
@@ -255,6 +346,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     }
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
+    if constexpr (LISTED) {
+        if (n <= kShortList) { listed_short(T, B, lutLds, bokehLds, samples, n, out); return; }
+    }
     float4 *pool0 = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords + wave * kPoolWaveWords);   // idx, o0x, o0y, packed
     uint4 *pool2 = reinterpret_cast<uint4 *>(pool0 + kPoolEntries);                                             // the ray's retry stream
 #if ZOIC_POOL_SLIM
@@ -623,7 +717,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
 #define ZOIC_POOL_PARAMS const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, \
         uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,        \
         uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList,             \
-        unsigned int *__restrict__ redoCount
+        unsigned int *__restrict__ redoCount, unsigned int *__restrict__ clearCursor
 #define ZOIC_POOL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_, LISTED_)                                                               \
     template <int NS, bool DEAD, bool IMAGE>                                                                                 \
     __global__ __launch_bounds__(kRefillBlock) ATTR_ void NAME_(ZOIC_POOL_PARAMS)                                             \
@@ -641,7 +735,7 @@ ZOIC_POOL_KERNEL(kolb_pool_guard_kernel, ZOIC_POOL_ATTR_FAST, false, true, false
 // one dword per sample of a launch)
 template <bool DEAD, bool IMAGE>
 int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
-                          uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_workCursor,
+                          uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_cursorPair, unsigned *parity,
                           int mode, uint32_t *d_scratch, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -650,8 +744,10 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
     uint32_t *d_redoList = d_scratch;
     for (uint64_t done = 0; done < n; done += kMaxPerLaunch) {
         const uint64_t m = (n - done < kMaxPerLaunch) ? (n - done) : kMaxPerLaunch;
-        hipError_t e = reset_work_cursors(d_workCursor, st);   // both cursor sets and the work list's counter
-        if (e != hipSuccess) return static_cast<int>(e);
+        hipError_t e = hipSuccess;
+        unsigned int *d_workCursor = d_cursorPair + (*parity & 1u) * kCursorBlockWords;          // zero: cleared by the previous launch's workgroup 0
+        unsigned int *d_clearCursor = d_cursorPair + ((*parity & 1u) ^ 1u) * kCursorBlockWords;
+        *parity ^= 1u;
         const unsigned grid = persistent_grid(m, kWavesPerBlock);
         const WorkGrain grain = work_grain(m, mode == 0 ? 256u : 512u);
         const uint32_t chunkRays = grain.chunkRays, chunksPerPart = grain.chunksPerPart;
@@ -665,7 +761,7 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
         unsigned int *redoCount = d_workCursor + kRedoCountOffset, *redoCursor = d_workCursor + kRedoCursorOffset;
 #define ZOIC_LAUNCH_POOL(KERNEL_, NS_, CURSOR_, GUARD_)                                                                          \
     hipLaunchKernelGGL((KERNEL_<NS_, DEAD, IMAGE>), dim3(grid), dim3(kRefillBlock), lds_bytes(GUARD_), st, table, bokeh, sp, rp, rayBase + done, \
-                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, kMinSearching, d_redoList, redoCount)
+                       static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, kMinSearching, d_redoList, redoCount, d_clearCursor)
 #define ZOIC_LAUNCH_POOL_BY_COUNT(KERNEL_, CURSOR_, GUARD_)                                                                      \
     switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                   \
     case 7: ZOIC_LAUNCH_POOL(KERNEL_, 7, CURSOR_, GUARD_); break;                                                               \
