@@ -1,11 +1,14 @@
+#!/bin/bash
+# tools/prof_pipeline.sh [configs] [mode]: per-kernel split of a Kolb launch (rocprofv3 kernel trace of tools/kbench.py); run on the GPU box
+cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
-for m in fast unchecked strict; do
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_c2_$m -- python tools/kbench.py --configs C2 --modes $m > /dev/null 2>&1
-python - $m <<PY
-import csv,glob,sys
-for f in glob.glob("gpurun_out/trace_c2_%s/*/*kernel_stats.csv" % sys.argv[1]):
+C=${1:-C2,C3,C5}; M=${2:-fast}
+rm -rf gpurun_out/trace_pipe
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_pipe -- python tools/kbench.py --configs $C --modes $M --steps 10 > /dev/null 2>&1
+python - <<PY
+import csv, glob
+for f in glob.glob("gpurun_out/trace_pipe/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        if "kolb" in r["Name"] or "fill" in r["Name"]: print(sys.argv[1], r["Name"][:60], r["Calls"], "%.1f" % (float(r["AverageNs"])/1e3))
+        if "kolb" in r["Name"] or "fill" in r["Name"]:
+            print("%-72s calls %4s  avg %.1f us" % (r["Name"][:72], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
-done
-ZOIC_DEBUG_LISTS=1 python tools/kbench.py --configs C2 --modes fast --steps 1 2>&1 | grep "handed" | tail -1

@@ -230,16 +230,20 @@ __device__ __forceinline__ bool mask_bit(unsigned long long m, uint32_t lane) { 
 // trace), no pool, no shortcuts -- and the first success in try order wins; TIR bumps count for the tries before it only.
 // Same device functions, same per-ray streams: the same bits as the pool path.
 constexpr uint32_t kShortList = 1u << 17;
+#ifndef ZOIC_SHORT_GROUP
+#define ZOIC_SHORT_GROUP 16   // lanes (= tries evaluated side by side) per listed ray: 4 / 8 / 16
+#endif
+constexpr uint32_t kShortGroup = ZOIC_SHORT_GROUP, kShortRaysPerWave = 64u / kShortGroup;
 __device__ __forceinline__ void listed_short(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
                                              const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out)
 {
-    const uint32_t lane = threadIdx.x & 63u, j = lane & 3u, g = lane >> 2;
+    const uint32_t lane = threadIdx.x & 63u, j = lane % kShortGroup, g = lane / kShortGroup;
     const uint32_t wavesTotal = gridDim.x * kWavesPerBlock, waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t *list = ZOIC_KARG(redoList);
     const uint4 *states = ZOIC_KARG(rngStates);
     const uint64_t rayBase = ZOIC_KARG(rayBase);
     uint32_t succ = 0, vign = 0, tir = 0;   // per lane; reduced at the end
-    for (uint32_t first = waveId * 16u; first < n; first += wavesTotal * 16u) {
+    for (uint32_t first = waveId * kShortRaysPerWave; first < n; first += wavesTotal * kShortRaysPerWave) {
         const uint32_t li = first + g;
         const bool have = li < n;
         const uint32_t idx = list[have ? li : n - 1u];
@@ -251,8 +255,8 @@ __device__ __forceinline__ void listed_short(const KolbTable &T, const BokehTabl
         else rng = rng_for_ray(T.seed, rayBase + idx);
         for (uint32_t a = 1; a < j; ++a) { (void)xor128(rng); (void)xor128(rng); }   // lane j >= 1 starts at draw 2 (j - 1)
         bool done = !have;
-        for (uint32_t round = 0; round < 7u; ++round) {
-            const uint32_t k = 4u * round + j;                       // this lane's try: 0 = the sample's own lens point, k = tries
+        for (uint32_t round = 0; round * kShortGroup <= static_cast<uint32_t>(kMaxTries) + 1u; ++round) {
+            const uint32_t k = kShortGroup * round + j;                      // this lane's try: 0 = the sample's own lens point, k = tries
             const bool valid = !done && k <= static_cast<uint32_t>(kMaxTries) + 1u;
             V3 o = o0, d{0.0f, 0.0f, 1.0f};
             uint32_t tirTry = 0;
@@ -274,15 +278,15 @@ __device__ __forceinline__ void listed_short(const KolbTable &T, const BokehTabl
                 }
                 ok = trace_lens_strict(T, o, d, tirTry);
             }
-            // the next try of this lane, k + 4, starts at draw 2 (k + 3): six draws past where this try ended (2 k; try 0 drew nothing)
-            for (int a = 0; a < 3; ++a) { (void)xor128(rng); (void)xor128(rng); }
+            // the next try of this lane, k + G, starts at draw 2 (k + G - 1): G - 1 pairs past where this try ended (2 k; try 0 drew nothing)
+            for (uint32_t a = 0; a + 1u < kShortGroup; ++a) { (void)xor128(rng); (void)xor128(rng); }
             // the group's decision, in try order
             const unsigned long long okAll = __ballot(valid && ok);
-            const uint32_t okGroup = static_cast<uint32_t>(okAll >> (4u * g)) & 15u;
-            const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : 4u;   // lowest try that got through
+            const uint32_t okGroup = static_cast<uint32_t>(okAll >> (kShortGroup * g)) & ((1u << kShortGroup) - 1u);
+            const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : kShortGroup;   // lowest try that got through
             if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
             const bool last = k == static_cast<uint32_t>(kMaxTries) + 1u;      // try 26 failed as well: weight 0, ITS partial state
-            if (valid && (j == winner || (winner == 4u && last))) {
+            if (valid && (j == winner || (winner == kShortGroup && last))) {
                 // try 26 is still traced by the loop condition (zoic.cpp:1927) and hands out its state, but tries > 25 is weight 0
                 // whether it got through or not (zoic.cpp:1951-1957)
                 const bool okRay = j == winner && !last;
@@ -292,7 +296,7 @@ __device__ __forceinline__ void listed_short(const KolbTable &T, const BokehTabl
                                  (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6));
                 if (okRay) ++succ; else ++vign;
             }
-            done = done || winner != 4u || 4u * round + 3u >= static_cast<uint32_t>(kMaxTries) + 1u;
+            done = done || winner != kShortGroup || kShortGroup * (round + 1u) > static_cast<uint32_t>(kMaxTries) + 1u;
             if (__ballot(!done) == 0ull) break;
         }
     }
@@ -322,7 +326,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         if (n == 0u) return;
         // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times over
         redoChunk = n > (1u << 20) ? 256u : 64u;
-        const uint32_t totalChunks = n <= kShortList ? (n + 15u) / 16u : (n + redoChunk - 1u) / redoChunk;   // short lists: 16 rays per wave (listed_short)
+        const uint32_t totalChunks = n <= kShortList ? (n + kShortRaysPerWave - 1u) / kShortRaysPerWave : (n + redoChunk - 1u) / redoChunk;   // short lists: listed_short
         if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed for it
         redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
     }
