@@ -221,12 +221,13 @@ __device__ __forceinline__ uint32_t mask_rank(unsigned long long m)   // exclusi
 }
 __device__ __forceinline__ bool mask_bit(unsigned long long m, uint32_t lane) { return ((m >> lane) & 1ull) != 0ull; }
 
-// listed_short: the STRICT evaluation of a SHORT work list (kShortList rays or fewer), four tries of a ray side by side.
+// listed_short: the STRICT evaluation of a SHORT work list (kShortList rays or fewer), G = 16 tries of a ray side by side.
 // The decision-safe launch ends with the STRICT kernel over the rays the FAST kernel could not decide; on all but the fisheye
 // that list is a few thousand rays and the kernel's time is not work but ONE ray's chain of sequential tries (up to 27 passes
 // of ~5 us at one wave per SIMD: 80 us of a 570 us TESSAR frame, 80 us on top of a 110 us 1 M-ray bucket).  The tries of a ray
-// are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1), so lanes 4g .. 4g+3 of a wave evaluate
-// tries 4r .. 4r+3 of ray g in round r -- the reference's own loop body (zoic.cpp:1870-1947: lens sample, direction, branchy
+// are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1), so the G lanes of group g of a wave evaluate
+// tries G r .. G r + G - 1 of ray g in round r (two rounds at most; G = 4 / 8 / 16 measured: 180 / 155 / 144 us for a 1 M-ray
+// decision-safe TESSAR bucket, 191 with the pool path) -- the reference's own loop body (zoic.cpp:1870-1947: lens sample, direction, branchy
 // trace), no pool, no shortcuts -- and the first success in try order wins; TIR bumps count for the tries before it only.
 // Same device functions, same per-ray streams: the same bits as the pool path.
 constexpr uint32_t kShortList = 1u << 17;
