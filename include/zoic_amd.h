@@ -127,6 +127,9 @@ int         zoic_abi_version(void);
 const char *zoic_status_string(zoic_status);
 const char *zoic_last_error_string(void);          /* thread-local detail of the last failure */
 int         zoic_device_count(void);               /* gfx950 devices visible to HIP */
+/* NUMA node of the host the device hangs off (sysfs, via its PCI bus id), -1 if unknown: render threads that call
+ * zoic_camera_create_ray save ~1 us per call when they run on that node */
+int         zoic_device_numa_node(int device);
 
 /* ---- node lifetime ------------------------------------------------------------------------- */
 /* node_parameters defaults, zoic.cpp:1547-1562 */

@@ -1,7 +1,9 @@
 /* sample_latency.c -- latency of zoic_camera_create_ray (the per-sample signature of zoic.cpp:1752) as a render thread sees it.
  *   sample_latency <lens.dat> [threads=1] [calls=200000] [precision 0|1|2] [lensModel 0|1]
  * prints one JSON line: median / p90 / p99 / mean microseconds per call (per thread) and the aggregate call rate. */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,6 +24,27 @@ static double now_us(void)
 }
 
 static int cmp(const void *a, const void *b) { const double x = *(const double *)a, y = *(const double *)b; return (x > y) - (x < y); }
+
+/* run on the CPUs of the NUMA node the GPU hangs off (worth ~1 us per call); returns the node or -1 */
+static int pin_to_gpu_node(void)
+{
+    const int node = zoic_device_numa_node(0);
+    if (node < 0) return -1;
+    char path[128], list[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    if (!fgets(list, sizeof list, f)) { fclose(f); return -1; }
+    fclose(f);
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(NULL, ",\n")) {
+        int a, b;
+        if (sscanf(tok, "%d-%d", &a, &b) == 2) { for (int c = a; c <= b; ++c) CPU_SET(c, &set); }
+        else if (sscanf(tok, "%d", &a) == 1) CPU_SET(a, &set);
+    }
+    return sched_setaffinity(0, sizeof set, &set) == 0 ? node : -1;
+}
 
 static void *worker(void *arg)
 {
@@ -55,6 +78,7 @@ int main(int argc, char **argv)
     p.lensDataPath = argv[1]; p.lensModel = model; p.focalLength = 5.0f; p.fStop = 2.8f;
     if (zoic_camera_create(0, &cam) != ZOIC_OK || zoic_camera_update(cam, &p) != ZOIC_OK ||
         zoic_camera_set_precision(cam, (zoic_precision)precision) != ZOIC_OK) { fprintf(stderr, "camera: %s\n", zoic_last_error_string()); return 2; }
+    const int node = pin_to_gpu_node();   /* inherited by the worker threads */
     lat = malloc(sizeof(double) * (size_t)threads * calls);
     pthread_t th[256];
     const double t0 = now_us();
@@ -68,8 +92,8 @@ int main(int argc, char **argv)
     zoic_counters c;
     zoic_camera_get_counters(cam, &c);
     printf("{\"threads\": %d, \"calls_per_thread\": %d, \"precision\": %d, \"lensModel\": %d, \"median_us\": %.2f, \"p90_us\": %.2f, \"p99_us\": %.2f, "
-           "\"mean_us\": %.2f, \"calls_per_s\": %.0f, \"rays_counted\": %llu}\n", threads, calls, precision, model, lat[n / 2], lat[n * 9 / 10],
-           lat[n * 99 / 100], mean / n, (double)(n + 2000.0 * threads) / wall * 1e6, (unsigned long long)(c.succesRays + c.vignettedRays));
+           "\"mean_us\": %.2f, \"calls_per_s\": %.0f, \"rays_counted\": %llu, \"numa_node\": %d}\n", threads, calls, precision, model, lat[n / 2], lat[n * 9 / 10],
+           lat[n * 99 / 100], mean / n, (double)(n + 2000.0 * threads) / wall * 1e6, (unsigned long long)(c.succesRays + c.vignettedRays), node);
     zoic_camera_destroy(cam);
     return 0;
 }

@@ -72,6 +72,7 @@ SYMBOLS = {
     "zoic_status_string": (C.c_char_p, [C.c_int]),
     "zoic_last_error_string": (C.c_char_p, []),
     "zoic_device_count": (C.c_int, []),
+    "zoic_device_numa_node": (C.c_int, [C.c_int]),
     "zoic_params_default": (None, [C.POINTER(Params)]),
     "zoic_camera_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "zoic_camera_destroy": (None, [_vp]),

@@ -667,6 +667,20 @@ int zoic_device_count(void)
     return n;
 }
 
+int zoic_device_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = static_cast<char>(*c - 'A' + 'a');   // sysfs spells bus ids in lower case
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    return node;
+}
+
 void zoic_params_default(zoic_params *p)  // node_parameters, zoic.cpp:1547-1562
 {
     if (!p) return;
