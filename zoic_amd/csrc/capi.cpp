@@ -583,7 +583,8 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
         lk = std::unique_lock<std::mutex>(slot->m);
     }
     (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error of this call
-    // always through the event (free on the stream that recorded it): a stream handle can be destroyed and its address reused
+// always through the event -- a stream handle can be destroyed and its address reused; on the stream that recorded it the
+    // wait is free (measured: no difference on the 8.3 M-ray thin-lens frame or a 1 M-ray Kolb bucket)
     if (slot->recorded) ZOIC_HIP(hipStreamWaitEvent(stream, slot->done, 0));
     if (needList && slot->redo.cap < listEntries) {
         // growing the scratch frees the old one: the slot's previous launch must be over (rare: first use / a larger batch)
