@@ -1,30 +1,29 @@
 #!/bin/bash
-# tools/pmc_extra.sh <tag> [bench args]: extra SQ PMC passes (issue mix, ifetch, branches) for bottleneck hunting; run on the GPU box.
-# TA_*/TCP_* counter groups hung rocprofv3 on this pool (a 15-minute timeout in round 1): not collected; every pass runs under `timeout`.
-set -u
-TAG=$1; shift
+# tools/pmc_extra.sh <config> [precision]: extra PMC groups (memory pipeline, instruction fetch, instruction classes) of the headline kernel
+cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
-OUT=gpurun_out/pmcx_$TAG
-mkdir -p $OUT
-BENCH="python bench.py --steps 3 --warmup 1 --only-headline $*"
+C=${1:-C3}; P=${2:-fast}
+OUT=gpurun_out/pmcx_${C}_$P
+rm -rf $OUT; mkdir -p $OUT
 i=0
-for grp in "SQ_INST_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_BRANCH SQ_IFETCH SQ_IFETCH_LEVEL SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_WAVE_CYCLES" \
-           "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_INST_CYCLES_SMEM" \
-           "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT64 SQ_INSTS_SALU" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+for grp in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM" \
+           "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_BRANCH" \
+           "SQ_IFETCH SQ_IFETCH_LEVEL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_BUSY_CYCLES SQ_CYCLES SQ_LEVEL_WAVES" \
+           "TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCC_REQ_sum TCC_BUSY_avr TCC_TAG_STALL_sum"; do
   i=$((i+1))
-  timeout 180 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/pmc$i.log 2>&1 || echo "pmc group $i failed: $grp" >> $OUT/errors.txt
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc$i -- python bench.py --steps 5 --warmup 2 --only-headline --config $C --precision $P > $OUT/pmc$i.log 2>&1 || echo "group $i failed"
 done
-python - $OUT <<'PY'
-import csv, glob, sys, collections
+python - <<PY
+import csv, glob, collections
 tot = {}
-for d in sorted(glob.glob(sys.argv[1] + "/pmc*/*/*_counter_collection.csv")):
+for d in sorted(glob.glob("$OUT/pmc*/*/*_counter_collection.csv")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(d)):
-        if "kolb" in r["Kernel_Name"]:
+        if "kolb_pool" in r["Kernel_Name"] and "listed" not in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         tot[k] = sum(v) / len(v)
-for k in sorted(tot): print("%-44s %.4g" % (k, tot[k]))
+for k in sorted(tot):
+    print("%-36s %.5g" % (k, tot[k]))
 PY
-cat $OUT/errors.txt 2>/dev/null

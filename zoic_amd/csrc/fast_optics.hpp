@@ -129,26 +129,31 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
 //   1 - cs2 = (1 - eta^2) + (eta/R)^2 thc^2 = (eta/R)^2 q,   q = thc^2 + (1 - eta^2) R^2 / eta^2,   TIR <=> q < 0,
 //   u' = eta u + kr (c - hit),   kr = (eta cos(i) - sqrt(1 - cs2)) / R = eta/(|R| R) (thc - sqrt(q))      (|u'| = 1 again).
 // The squared distance of the origin from the axis is carried from interface to interface (it is the h^2 of the previous
-// hit): |L|^2 = h^2 + Lz^2.  Per interface: 27 VALU + 2 v_sqrt_f32 + 3 compares (4 with a guard band).
+// hit): |L|^2 = h^2 + Lz^2.  Per interface: 26 VALU + 2 v_sqrt_f32 incl. 2 compares (3 with a guard band): a sphere miss needs none of its own (fast_hit).
 //
 // FastHit: the arithmetic of ONE interface, shared by the predicated trace, the branchy trace and the interface-0 test, so that
 // the three agree bit for bit on every decision.
-struct FastHit { float w, thc, h2; V3 hit; bool miss; };
+struct FastHit { float w, thc, h2, tca; V3 hit; };
 __device__ __forceinline__ FastHit fast_hit(const FastSurface &S, const V3 &o, float oAxis2, const V3 &u)
 {
     FastHit r;
     const float Lz = S.center - o.z;
     const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
     const float d2 = (oAxis2 + Lz * Lz) - tca * tca;
-    const float rd = S.radius2 - d2;
-    r.miss = rd < 0.0f;                                     // d2 > radius2 (zoic.cpp:981)
-    r.w = fabsf(rd);                                        // thc^2
+    r.tca = tca;
+    // A ray that MISSES the sphere (d2 > radius2, zoic.cpp:981) takes the root of a negative number: thc, the hit point and h^2
+    // are NaN, and every clip test below is written !(h2 <= limit) -- true for NaN -- so the miss needs no compare of its own.
+    // (A ray that ARRIVES as NaN -- a lens sample at the disk mapping's 0/0 centre, zoic.cpp:697-699 -- passes every `>` of the
+    // reference and comes out a NaN success; it is recognised by its NaN tca at the first interface, is_nan_ray.)
+    r.w = S.radius2 - d2;                                   // thc^2
     r.thc = fsqrt_fast(r.w);
     const float t = tca + r.thc * S.sign;
     r.hit = V3{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
     r.h2 = r.hit.x * r.hit.x + r.hit.y * r.hit.y;
     return r;
 }
+__device__ __forceinline__ bool is_nan_ray(const FastHit &h) { return h.tca != h.tca; }
+
 // Snell at the hit point: returns q (TIR <=> q < 0) and writes the refracted unit direction
 __device__ __forceinline__ float fast_refract(const FastSurface &S, const FastHit &h, V3 &u)
 {
@@ -168,8 +173,8 @@ __device__ __forceinline__ bool surface_is_guarded(const FastSurface &S) { retur
 __device__ __forceinline__ int fast_interface(const FastSurface &S, V3 &o, float &oAxis2, V3 &u, bool *near = nullptr)
 {
     const FastHit h = fast_hit(S, o, oAxis2, u);
-    if (near) *near = (h.h2 > S.housingLo) & !(h.h2 > S.housingHi);
-    if (h.miss | (h.h2 > S.housing2)) return 1;              // the stop's housing2 includes the user aperture
+    if (near) *near = !(h.h2 <= S.housingLo) & (h.h2 <= S.housingHi);
+    if (!(h.h2 <= S.housing2) && !is_nan_ray(h)) return 1;   // sphere miss (NaN h2) or housing clip; the stop's housing2 includes the user aperture
     o = h.hit;
     oAxis2 = h.h2;
     V3 un = u;
@@ -188,12 +193,12 @@ __device__ __forceinline__ bool interface0_clear_fast(const FastSurface &S, V3 o
     const V3 u{d.x * inv, d.y * inv, d.z * inv};
     const FastHit h = fast_hit(S, o, o.x * o.x + o.y * o.y, u);
     if constexpr (GUARD) {
-        const bool aboveLo = h.h2 > S.housingLo;
-        near = aboveLo & !(h.h2 > S.housingHi);
-        return !(h.miss | aboveLo);
+        const bool insideLo = h.h2 <= S.housingLo;           // false for a sphere miss (NaN)
+        near = !insideLo & (h.h2 <= S.housingHi);
+        return insideLo | is_nan_ray(h);
     } else {
         near = false;
-        return !(h.miss | (h.h2 > S.housing2));
+        return (h.h2 <= S.housing2) | is_nan_ray(h);
     }
 }
 
@@ -244,6 +249,7 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
     V3 u{d.x * inv, d.y * inv, d.z * inv};
     float oAxis2 = o.x * o.x + o.y * o.y;
     unsigned long long alive = alive0, tirSeen = 0ull, unsure = 0ull;   // alive0: lanes without a candidate ride along dead
+    unsigned long long nanRays = 0ull;                                  // candidates that arrived as NaN: they "pass" everything
     // The table words of interface i + 1 are requested BEFORE interface i is evaluated (scalar loads return out of order, so
     // the only wait there is is lgkmcnt(0): `surface_arrived` takes it at the end of interface i, a whole interface -- ~30 VALU --
     // after the request; the sched_barrier keeps the scheduler from sinking the request towards its use).  Loading at the use
@@ -258,14 +264,14 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
             if (i + 1 < NS) { Sn = load_surface<true>(surf, i + 1); __builtin_amdgcn_sched_barrier(0); }   // the request goes out HERE
         }
         const FastHit h = fast_hit(S, o, oAxis2, u);
-        unsigned long long clipped = __ballot(h.miss);
+        if (i == 0) nanRays = __ballot(is_nan_ray(h));
+        unsigned long long clipped;   // sphere miss or housing clip: ONE compare (a miss makes h2 NaN, fast_hit)
         if constexpr (GUARD) {
-            // two compares: above the band's lower edge = clipped or too close to call; not above its upper edge as well =
+            // two compares: not inside the band's lower edge = clipped or too close to call; inside its upper edge as well =
             // too close to call (then the ray goes to STRICT and `clipped` is never used).  Unguarded: both edges = housing2.
-            const unsigned long long aboveLo = __ballot(h.h2 > S.housingLo);
-            unsure |= alive & aboveLo & ~__ballot(h.h2 > S.housingHi);
-            clipped |= aboveLo;
-        } else clipped |= __ballot(h.h2 > S.housing2);   // the stop's housing2 includes the user aperture
+            clipped = ~__ballot(h.h2 <= S.housingLo);
+            unsure |= alive & clipped & __ballot(h.h2 <= S.housingHi);
+        } else clipped = ~__ballot(h.h2 <= S.housing2);   // the stop's housing2 includes the user aperture
         o = h.hit;
         oAxis2 = h.h2;
         const unsigned long long tirHere = __ballot(fast_refract(S, h, u) < 0.0f);
@@ -278,7 +284,7 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
     tirMask = tirSeen;
     unsureMask = unsure;
     d = u;
-    return alive;
+    return alive | (alive0 & nanRays);
 }
 
 }  // namespace zoic
