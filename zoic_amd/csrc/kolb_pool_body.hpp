@@ -196,6 +196,9 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #ifndef ZOIC_POOL_SLIM
 #define ZOIC_POOL_SLIM 0   // 1: 40-byte entries: the exit-pupil scale / translation are looked up again when a ray is popped
 #endif
+#ifndef ZOIC_SEARCH_DRAWS
+#define ZOIC_SEARCH_DRAWS 2   // lens draws the retry search of the IMAGE kernels samples per round (one wait for all their records); measured on C3: 1 -> 38.8, 2 -> 41.1, 3 -> 40.4, 4 -> 39.6 Grays/s
+#endif
 constexpr uint32_t kPoolEntries = 128;
 constexpr uint32_t kPoolWaveWords = kPoolEntries * (ZOIC_POOL_SLIM ? 10u : 12u);
 constexpr uint32_t kPoolListWords = 128;
@@ -532,6 +535,36 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                     if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
                     else rng = rng_for_ray(kernarg_field<uint32_t, offsetof(KolbKernelArgs, T) + offsetof(KolbTable, seed)>(), ZOIC_KARG(rayBase) + idx);
                 }
+                if constexpr (IMAGE && ZOIC_SEARCH_DRAWS > 1) {
+                    // several draws per round: their column records are all requested before the first is read, so a round waits
+                    // for memory once; a later draw counts (tries, retry stream) only when the ones before it were rejected with
+                    // tries to spare -- exactly the reference's sequence
+                    constexpr int kDraws = ZOIC_SEARCH_DRAWS;
+                    Rng after[kDraws];
+                    float vCol[kDraws];
+                    CellProbe probes[kDraws];
+                    Rng r = rng;
+#pragma unroll
+                    for (int j = 0; j < kDraws; ++j) {
+                        const float uj = rng_unit(xor128(r));   // zoic.cpp:1930
+                        vCol[j] = rng_unit(xor128(r));
+                        after[j] = r;
+                        probes[j] = bokeh_cells_issue(B, bokehLds, T.bokehH, uj, vCol[j]);
+                    }
+                    bool open = true;
+#pragma unroll
+                    for (int j = 0; j < kDraws; ++j) {
+                        if (open) {
+                            ++tries; rng = after[j];
+                            d = retry_direction(T, bokeh_cells_finish<STRICT>(B, T.bokehW, T.bokehH, vCol[j], probes[j]), o0x, o0y, maxScale, translation, sn, cs);
+                            bool near0;
+                            const bool pass0 = clears_rear(o, d, near0);
+                            if (GUARD && near0) { unsure = true; searching = false; open = false; }
+                            else if (pass0) { cand = true; searching = false; open = false; }
+                            else if (tries > static_cast<uint32_t>(kMaxTries)) { searching = false; open = false; }
+                        }
+                    }
+                } else {
                 const float u = rng_unit(xor128(rng));   // zoic.cpp:1930
                 const float v = rng_unit(xor128(rng));
                 ++tries;
@@ -541,6 +574,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 if (GUARD && near0) { unsure = true; searching = false; }
                 else if (pass0) { cand = true; searching = false; }
                 else if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
+                }
             }
         }
 
