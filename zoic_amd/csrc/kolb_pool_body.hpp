@@ -180,7 +180,12 @@ __device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehT
 static __device__ unsigned long long g_passStats[8];   // A passes, B passes, search iterations, sum looking lanes, traces, sum cand lanes, sum active lanes, finished
 static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles per region of the pass loop, summed over all waves
 #define ZOIC_PS_DECL unsigned long long ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt[16] = {}, rtLast = __builtin_readcyclecounter();
+#ifdef ZOIC_PS_LIST   // the work list instead: [0] rays listed, [1] sum of their tries when listed, [2] rays the LISTED kernel finished, [3] sum of their final tries
+#define ZOIC_PS_ADD(I, V)
+#define ZOIC_PS_LISTADD(I, V) ps[I] += (V);
+#else
 #define ZOIC_PS_ADD(I, V) ps[I] += (V);
+#endif
 #define ZOIC_MARK(N) { const unsigned long long rtNow = __builtin_readcyclecounter(); rt[N] += rtNow - rtLast; rtLast = rtNow; }
 #define ZOIC_PS_FLUSH if (lane == 0) { for (int r = 0; r < 8; ++r) atomicAdd(&g_passStats[r], ps[r]); for (int r = 0; r < 16; ++r) atomicAdd(&g_regionCycles[r], rt[r]); }
 #else
@@ -188,6 +193,9 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #define ZOIC_PS_ADD(I, V)
 #define ZOIC_MARK(N)
 #define ZOIC_PS_FLUSH
+#endif
+#ifndef ZOIC_PS_LISTADD
+#define ZOIC_PS_LISTADD(I, V)
 #endif
 
 // LDS per wave: the pool, 128 entries stored piece-major (arrays of 128 x 16 / 16 / 8 bytes: a push or pop is two
@@ -652,6 +660,16 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             vign += nv;                                                                       // zoic.cpp:1951-1957
             succ += static_cast<uint32_t>(__popcll(__ballot(finished))) - nv;
             ZOIC_PS_ADD(7, __popcll(__ballot(finished)))
+#ifdef ZOIC_PS_LIST
+            if constexpr (LISTED) {
+                ZOIC_PS_LISTADD(2, __popcll(__ballot(finished)))
+                for (uint32_t b = 0; b < 5u; ++b) ZOIC_PS_LISTADD(3, static_cast<unsigned long long>(__popcll(__ballot(finished && ((tries >> b) & 1u)))) << b)
+            }
+            if constexpr (GUARD) {
+                ZOIC_PS_LISTADD(0, __popcll(__ballot(dropU)))
+                for (uint32_t b = 0; b < 5u; ++b) ZOIC_PS_LISTADD(1, static_cast<unsigned long long>(__popcll(__ballot(dropU && ((tries >> b) & 1u)))) << b)
+            }
+#endif
         }
         if (finished) {
             float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;
