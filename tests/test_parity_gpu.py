@@ -727,6 +727,97 @@ def test_fast_parameter_fuzz(gpu, oracle_lib):
     print("fast-mode fuzz: worst direction RMSE %.3g, worst flip fraction %.3g" % (worst["rmse"], worst["flip"]))
 
 
+@pytest.mark.parametrize("shape", [(7, 2), (16, 2), (2, 9), (5, 31)])
+def test_retry_dead_bound_with_a_bokeh_image_that_is_not_square(gpu, oracle_lib, shape):
+    """bokehSample centres columns with the image HEIGHT and rows with its WIDTH (zoic.cpp:441,466), so an image that is
+    not square returns lens samples far outside the unit square (2 x 7 pixels: x in [-3, -2]).  The retry-dead shortcut
+    bounds the disk the retries can sample; with the unit-square bound it declared PETZVAL rays dead that the reference
+    gets through on their 2nd ... 12th try (found by test_bokeh_image_fuzz).  The bound is the image's own now
+    (KolbTable::retryLensK)."""
+    h, w = shape
+    lum = np.random.RandomState(0).rand(h, w).astype(np.float32)
+    img = np.repeat(lum[:, :, None], 3, axis=2).astype(np.float32)
+    p = dict(lensModel=RAYTRACED, lensDataPath=lens_path("petzval_f1.25.dat"), focalLength=8.0, fStop=2.0, focalDistance=100.0, sensorWidth=3.0,
+             sensorHeight=2.0, kolbSamplingLUT=True, useImage=True, bokehPath="mem:notsquare%dx%d" % (w, h))
+    cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+    cam.set_bokeh_image(img); oc.set_bokeh_image(img)
+    cam.update(**p); oc.update(**p)
+    n = 1 << 15
+    for where in (0.5, 0.1):
+        s, base = slab("C3", n, where)
+        ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=1, ray_index_base=base), threads=8)
+        got = cam.create_rays(s, ray_index_base=base)
+        assert np.array_equal(got["flags"], ref["flags"])
+        g, r = got["planes"], ref["planes"]
+        assert ((bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))).all()
+    assert cam.counters() == oc.counters()
+
+
+def test_bokeh_image_fuzz(gpu, oracle_lib):
+    """Machine-made bokeh images behind machine-made cameras (the IMAGE instantiations of the Kolb kernels and the thin-lens
+    sampler): shape 2 ... 160 a side and not square, noise / a few bright spots / a falloff / black rows and columns,
+    every shipped prescription with a stop, LUT on and off.  Strict mode must stay bit-identical to the oracle (flags, every
+    plane, counters) -- in particular the retry search, which samples several draws of a ray's retry stream per round but
+    may only count the ones the reference's loop would have drawn (zoic.cpp:1927-1947, 420-485); the decision-safe fast
+    mode must keep its tolerance on the same camera."""
+    from hypothesis import given, settings, HealthCheck, strategies as st
+    lenses = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat", "triplet_f2.5.dat", "mori_f2.8.dat"]
+
+    @settings(max_examples=int(os.environ.get("ZOIC_FUZZ_EXAMPLES_IMAGE", os.environ.get("ZOIC_FUZZ_EXAMPLES", "60"))), deadline=None,
+              suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.sampled_from(lenses), st.floats(2.0, 12.0, width=32), st.floats(1.25, 11.0, width=32), st.floats(1.0, 5.0, width=32), st.booleans(),
+           st.sampled_from([RAYTRACED, RAYTRACED, RAYTRACED, THINLENS]), st.integers(2, 160), st.integers(2, 160),
+           st.sampled_from(["noise", "spots", "falloff", "gaps"]), st.floats(0.02, 0.98), st.integers(0, 2 ** 20))
+    def run(lens, focal, fstop, sensor_w, lut, model, h, w, kind, where, seed):
+        rs = np.random.RandomState(seed & 0xffff)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        if kind == "noise":
+            lum = rs.rand(h, w).astype(np.float32)
+        elif kind == "spots":
+            lum = 1e-4 * rs.rand(h, w).astype(np.float32)
+            for _ in range(4):
+                lum[rs.randint(h), rs.randint(w)] = 1.0
+        elif kind == "falloff":
+            lum = np.exp(-((xx - w / 2) ** 2 + (yy - h / 2) ** 2) / (0.03 * w * h + 1.0)).astype(np.float32) + 1e-6 * rs.rand(h, w).astype(np.float32)
+        else:   # black rows and columns: zero-mass rows sort to the tail of the row CDF, zero pixels to the tail of a column CDF
+            lum = rs.rand(h, w).astype(np.float32)
+            lum[rs.rand(h) < 0.3, :] = 0.0
+            lum[:, rs.rand(w) < 0.3] = 0.0
+            if not (lum > 0).any():
+                lum[h // 2, w // 2] = 1.0
+        img = np.repeat(lum[:, :, None], 3, axis=2).astype(np.float32)
+        p = dict(lensModel=model, lensDataPath=lens_path(lens), focalLength=focal, fStop=fstop, focalDistance=100.0, sensorWidth=sensor_w,
+                 sensorHeight=sensor_w / 1.5, kolbSamplingLUT=lut, useImage=True, bokehPath="mem:fuzz%dx%d_%d" % (w, h, seed))
+        cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+        cam.set_bokeh_image(img); oc.set_bokeh_image(img)
+        try:
+            oc.update(**p)
+        except oracle_lib.OracleError:
+            return
+        cam.update(**p)
+        cam.set_seed(seed)
+        n = 8192
+        s, base = slab("C3", n, where)
+        ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=seed, ray_index_base=base), threads=4)
+        refCounters = oc.counters()
+        got = cam.create_rays(s, ray_index_base=base)
+        assert np.array_equal(got["flags"], ref["flags"]), p
+        g, r = got["planes"], ref["planes"]
+        same = (bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))
+        assert same.all(), (p, int((~same.all(0)).sum()))
+        assert cam.counters() == refCounters, p
+        if model == RAYTRACED:
+            cam.set_precision(PRECISION_FAST)
+            fast = cam.create_rays(s, ray_index_base=base)
+            agree = fast["flags"] == ref["flags"]
+            assert 1.0 - float(agree.mean()) < 20 * FLIP_TOL, (p, 1.0 - float(agree.mean()))   # 8192 rays: one flip is 1.2e-4
+            live = agree & (ref["weight"] != 0)
+            if live.sum() > 100:
+                dd = fast["dir"][:, live].astype(np.float64) - ref["dir"][:, live]
+                assert float(np.sqrt((dd ** 2).sum(0).mean())) < DIR_RMSE_TOL, p
+    run()
+
+
 @pytest.mark.parametrize("cfg,extra", [("C5", {}), ("C1", dict(opticalVignettingDistance=3.0))])
 def test_batches_beyond_2_to_31_samples_are_split(gpu, cfg, extra):
     """One call with 2^31 + 70 000 samples (103 GB of samples + records): the persistent kernels use 32-bit ray offsets, so

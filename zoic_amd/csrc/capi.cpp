@@ -906,7 +906,7 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
 
     // flatten what the kernels read
     if (p->lensModel == ZOIC_RAYTRACED) {
-        cam->lens.fill_table(cam->kolb, p->sensorWidth);
+        cam->lens.fill_table(cam->kolb, p->sensorWidth, imageOn ? cam->image.x : 0, imageOn ? cam->image.y : 0);
         cam->kolb.useLUT = p->kolbSamplingLUT != 0;
         cam->kolb.useImage = imageOn;
         cam->kolb.bokehW = cam->image.x; cam->kolb.bokehH = cam->image.y;

@@ -109,7 +109,7 @@ __device__ __forceinline__ RaySetup setup_ray(const KolbTable &T, const float2 *
                 // retry-dead test (tables.hpp): can ANY retry of this ray reach the rear element?  The retries sample
                 // the disk of radius maxScale * |lens sample|max around the LUT centroid translated in BOTH components
                 // and rotated by the ray's (parabola) cos/sin; 1 % + 1e-4 of margin dwarfs every rounding involved.
-                const float k = T.useImage ? 1.4158f : 1.0023f;   // |lens sample| <= sqrt(2) (image) / 1.0011 (disk), x the rotation's 1.0011
+                const float k = T.retryLensK;   // |lens sample| x the rotation's 1.0011: 1.0023 for the disk, the image's own bound otherwise (tables.hpp)
                 const float ccx = r.translation * (r.cs - r.sn) - r.o0x * T.retryK1, ccy = r.translation * (r.sn + r.cs) - r.o0y * T.retryK1;
                 const float reach = (T.retryRho0 + dist * T.retrySpread + fabsf(r.maxScale) * k) * 1.01f + 1.0e-4f;
                 // |d.xy| of any retry <= |rotated, translated lens point| + |o.xy|: below retryMaxD the opposite cap is out of reach

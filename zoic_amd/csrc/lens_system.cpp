@@ -384,7 +384,20 @@ void LensSystem::build_lut(Rng &rng, LutTraceFn trace, void *user, LutBuildFn wh
     hasLUT = true;
 }
 
-void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
+// |lens sample| can be at most this (x 1.0011 for the parabola rotation that follows).  Disk mapping: |r| <= 1 times a parabola
+// cos/sin pair of norm <= 1.0011.  Bokeh image (zoic.cpp:441,466,479-480): x = (col - (H-1)/2) / W * 2, y = -(row - (W-1)/2) / H * 2
+// with col in [0, W-1], row in [0, H-1] and INTEGER halves -- width and height are swapped in the centring, so only a square
+// image stays inside the unit square.
+static float lens_sample_bound(int bokehW, int bokehH)
+{
+    if (bokehW <= 0 || bokehH <= 0) return 1.0011f * 1.0011f + 1.0e-4f;
+    const int c0 = (bokehH - 1) / 2, r0 = (bokehW - 1) / 2;
+    const double mx = 2.0 * std::max(std::abs(0 - c0), std::abs(bokehW - 1 - c0)) / bokehW;
+    const double my = 2.0 * std::max(std::abs(0 - r0), std::abs(bokehH - 1 - r0)) / bokehH;
+    return static_cast<float>(std::sqrt(mx * mx + my * my) * 1.0011 * 1.0001 + 1.0e-4);
+}
+
+void LensSystem::fill_table(KolbTable &t, float sensorWidth, int bokehW, int bokehH) const
 {
     fill_surfaces(t);
     t.halfSensor = sensorWidth * 0.5f;  // exact; sx*(sensorWidth*0.5) in f64 rounds once, like the f32 product
@@ -409,6 +422,7 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
     // n.d < 0 resp. > 0 against the sign of n.z -- possible only for |d.xy| / dirZ > sqrt(R^2 - a^2) / a.  retryMaxD is that
     // bound on |d.xy| (1 % margin); the per-ray test leaves rays that could exceed it to their 26 draws.
     t.retryOn = 0; t.retryK1 = t.retryRho0 = t.retrySpread = t.retryMaxD = 0.0f;
+    t.retryLensK = lens_sample_bound(bokehW, bokehH);
     if (hasLUT && !rows.empty() && kRetryDeadMinShare < 1.0) {
         const double R = rows[0].radius, a = std::sqrt(static_cast<double>(t.surf[0].housing2)), dirZ = t.dirZ, oz = originShift;
         if (a < std::fabs(R) && dirZ > 0.0) {
@@ -440,8 +454,8 @@ void LensSystem::fill_table(KolbTable &t, float sensorWidth) const
                 if (!lut_lookup(t, dist, maxScale, translation) || (maxScale == 0.0f && translation == 0.0f)) continue;   // dead pixels have their own shortcut
                 const float theta = std::atan2(o0y, o0x), sn = std::sin(theta), cs = std::cos(theta);
                 const float ccx = translation * (cs - sn) - o0x * t.retryK1, ccy = translation * (sn + cs) - o0y * t.retryK1;
-                const float reach = (t.retryRho0 + dist * t.retrySpread + std::fabs(maxScale) * 1.4158f) * 1.01f + 1.0e-4f;
-                const float dxyMax = std::fabs(maxScale) * 1.4158f + std::fabs(translation) * 1.4158f + dist;
+                const float reach = (t.retryRho0 + dist * t.retrySpread + std::fabs(maxScale) * t.retryLensK) * 1.01f + 1.0e-4f;
+                const float dxyMax = std::fabs(maxScale) * t.retryLensK + std::fabs(translation) * 1.4158f + dist;
                 if (ccx * ccx + ccy * ccy > reach * reach && dxyMax <= t.retryMaxD) ++hits;
             }
         if (hits < kRetryDeadMinShare * grid * grid) t.retryOn = 0;

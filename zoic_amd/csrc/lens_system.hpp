@@ -62,7 +62,8 @@ public:
     LensError prepare(float focalLength, float fStop, float focalDistance, bool useLUT, Rng &rng,
                       LutTraceFn trace = nullptr, void *traceUser = nullptr, LutBuildFn whole = nullptr);
     // flatten for the kernels
-    void fill_table(KolbTable &t, float sensorWidth) const;
+    // bokehW / bokehH: the bokeh image the lens samples come from (0: the concentric disk mapping) -- bounds the retry-dead test
+    void fill_table(KolbTable &t, float sensorWidth, int bokehW = 0, int bokehH = 0) const;
 
     std::vector<LensRow> rows;       // rear -> front after parse()
     int apertureElement = -1;

@@ -81,6 +81,9 @@ struct KolbTable {
     float retryMaxD;      // the bounds above hold for hits on the VERTEX-side cap of the rear sphere; the root the reference takes
                           // (zoic.cpp:986: ONE signed root, t < 0 never rejected) can only land on the opposite |xy| <= a cap
                           // when |d.xy| / dirZ > sqrt(R^2 - a^2) / a: rays with |d.xy| above retryMaxD are never classified
+    float retryLensK;     // bound of |lens sample| x the parabola rotation's 1.0011: 1.0023 for the disk mapping; for a bokeh image
+                          // what zoic.cpp:441,466 can return -- the centring swaps width and height, so an image that is not
+                          // square samples far outside the unit square (2 x 7 pixels: x in [-3, -2])
     Surface surf[kMaxSurfaces];
     FastSurface fsurf[kMaxSurfaces];
     float lutMaxScale[kLutEntries];  // boundingBox2d::getMaxScale per LUT entry (zoic.cpp:503-517)
