@@ -63,6 +63,14 @@ typedef enum zoic_precision {
                                   count / weight <= ~1e-6 of the rays (tests hold 5e-5); origin / direction differ in low-order bits */
     ZOIC_PRECISION_FAST_UNCHECKED = 2 /* FAST without the decision check (A/B; decisions flip where the reference's own f32
                                          rounding noise decides, ~1e-5 ... 1e-3 of the rays depending on the lens) */
+    /* Domain of the FAST modes: they drop the reference's per-interface renormalisations (the refracted direction stays unit
+       by construction as long as every hit lies ON its sphere to rounding), which holds while hits are the near-vertex roots
+       of a lens laid out rear -> front with the sensor behind it.  A prescription whose traced focal length is negative is
+       rescaled by a NEGATIVE focalLengthRatio (zoic.cpp:1651-1661: thicknesses and radii change sign), and one whose focus
+       computation puts the sensor in FRONT of the rear vertex (originShift >= lenses[0].thickness) sends its rays away from
+       the lens: the reference's one signed root (zoic.cpp:986, t < 0 never rejected) then lands far behind the ray, and the
+       hit-point rounding no longer is small against the radii.  Such a camera (zoic_lens_info::fastRunsStrict) runs STRICT in
+       every mode. */
 } zoic_precision;
 
 #define ZOIC_MAX_LENS_SURFACES 32
@@ -216,6 +224,7 @@ typedef struct zoic_lens_info {
     float lutKey[ZOIC_LUT_ENTRIES];
     float lutMaxX[ZOIC_LUT_ENTRIES], lutMaxY[ZOIC_LUT_ENTRIES], lutMinX[ZOIC_LUT_ENTRIES], lutMinY[ZOIC_LUT_ENTRIES];
     int32_t bokehWidth, bokehHeight;
+    int32_t fastRunsStrict; /* 1: this camera is outside the FAST modes' domain (see zoic_precision) and runs STRICT whatever the mode */
 } zoic_lens_info;
 zoic_status zoic_camera_get_info(const zoic_camera *cam, zoic_lens_info *out);
 /* copies of the bokeh CDF tables (bokehProbability, zoic.cpp:222-417); arrays sized by bokehWidth/Height */

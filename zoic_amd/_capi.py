@@ -62,7 +62,7 @@ class LensInfo(C.Structure):
                 + [(n, C.c_float * MAX_LENS_SURFACES) for n in ("curvature", "thickness", "ior", "aperture", "center")]
                 + [("lutSize", C.c_int32), ("lutKey", C.c_float * LUT_ENTRIES)]
                 + [(n, C.c_float * LUT_ENTRIES) for n in ("lutMaxX", "lutMaxY", "lutMinX", "lutMinY")]
-                + [("bokehWidth", C.c_int32), ("bokehHeight", C.c_int32)])
+                + [("bokehWidth", C.c_int32), ("bokehHeight", C.c_int32), ("fastRunsStrict", C.c_int32)])
 
 
 # every symbol include/zoic_amd.h declares: name -> (restype, argtypes)

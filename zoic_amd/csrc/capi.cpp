@@ -237,6 +237,13 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     float fov = 0, tanFov = 0, apertureRadius = 0;
     Rng stream{};                  // the xor128 function-static state (zoic.cpp:648): LUT build draws from it
     zoic_precision precision = ZOIC_PRECISION_STRICT;
+    bool fastDomain = true;   // RAYTRACED: the lens is inside the FAST modes' domain (include/zoic_amd.h, zoic_precision); else every mode runs STRICT
+    // kernel mode of a launch: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked
+    int kernel_mode() const
+    {
+        if (precision == ZOIC_PRECISION_STRICT || (params.p.lensModel == ZOIC_RAYTRACED && !fastDomain)) return 0;
+        return precision == ZOIC_PRECISION_FAST ? 1 : 2;
+    }
     uint32_t seed = 1;
     bool updated = false;
     bool lutOnHost = false, lutHostDraws = false;
@@ -561,7 +568,7 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
     const int model = cam->params.p.lensModel;
     if (model != ZOIC_RAYTRACED && model != ZOIC_THINLENS)
         return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
-    const int mode = cam->precision == ZOIC_PRECISION_STRICT ? 0 : (cam->precision == ZOIC_PRECISION_FAST ? 1 : 2);
+    const int mode = cam->kernel_mode();
     // the Kolb launch's scratch (kernels.hpp): decision-safe FAST's work list, the finish kernel's byte map
     const size_t listEntries = model == ZOIC_RAYTRACED ? kolb_scratch_dwords(cam->kolb, n, mode) : 0;
     const bool needList = listEntries != 0;
@@ -907,6 +914,11 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
     // flatten what the kernels read
     if (p->lensModel == ZOIC_RAYTRACED) {
         cam->lens.fill_table(cam->kolb, p->sensorWidth, imageOn ? cam->image.x : 0, imageOn ? cam->image.y : 0);
+        // the FAST modes' domain (include/zoic_amd.h): a lens laid out rear -> front (positive focalLengthRatio: thicknesses keep
+        // their signs) with the sensor BEHIND the rear vertex (z = lenses[0].thickness after cleanupLensData) and rays leaving it
+        // towards +z -- then every hit is the near-vertex root a short way ahead of the ray
+        cam->fastDomain = cam->lens.focalLengthRatio > 0.0f && std::isfinite(cam->lens.focalLengthRatio) && cam->kolb.dirZ > 0.0f &&
+                          !cam->lens.rows.empty() && cam->lens.originShift < cam->lens.rows[0].thickness;
         cam->kolb.useLUT = p->kolbSamplingLUT != 0;
         cam->kolb.useImage = imageOn;
         cam->kolb.bokehW = cam->image.x; cam->kolb.bokehH = cam->image.y;
@@ -1074,7 +1086,7 @@ static zoic_status mailbox_ensure_running(zoic_camera *cam, unsigned slot)
     }
     ZOIC_HIP(hipStreamSynchronize(M.stream));   // the previous resident kernel has retired (its last store is long done)
     const int model = cam->params.p.lensModel;
-    const int mode = cam->precision == ZOIC_PRECISION_STRICT ? 0 : (cam->precision == ZOIC_PRECISION_FAST ? 1 : 2);
+    const int mode = cam->kernel_mode();
     M.request(0)->stop = 0u;
     h->alive = 1u;
     std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -1238,6 +1250,7 @@ zoic_status zoic_camera_get_info(const zoic_camera *cam, zoic_lens_info *out)
         out->lutMinX[i] = L.lutBox[i].minX; out->lutMinY[i] = L.lutBox[i].minY;
     }
     out->bokehWidth = cam->image.x; out->bokehHeight = cam->image.y;
+    out->fastRunsStrict = (cam->params.valid && cam->params.p.lensModel == ZOIC_RAYTRACED && !cam->fastDomain) ? 1 : 0;
     return ZOIC_OK;
 }
 
