@@ -732,6 +732,52 @@ def test_fast_parameter_fuzz(gpu, oracle_lib):
     assert worst["strictOnly"] * 4 <= worst["cameras"]     # the shipped prescriptions are inside the domain but for odd focus settings
 
 
+def test_hostile_sample_fuzz(gpu, oracle_lib):
+    """Samples nobody should send, through cameras of every kind (both lens models, LUT on / off, bokeh image on / off, every
+    shipped prescription with a stop): zeros of both signs, 0.5 (the disk mapping's 0/0), 1.0 and its neighbours, negative
+    and > 1 lens samples, denormals, 1e30, infinities and NaNs in every component, mixed with ordinary samples in one
+    batch.  The reference has no input checks: whatever its arithmetic makes of them (NaN rays that 'pass' every compare,
+    LUT lookups off both ends -- fenced UB) the strict kernels must make too, bit for bit, counters included."""
+    from hypothesis import given, settings, HealthCheck, strategies as st
+    lenses = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat", "triplet_f2.5.dat", "mori_f2.8.dat"]
+    special = np.array([0.0, -0.0, 0.5, 1.0, -1.0, 0.99999994, 1.0000001, 0.49999997, 0.50000006, 1e-40, -1e-40, 1e-30, 1e30, -1e30,
+                        np.inf, -np.inf, np.nan, 2.0, -3.0, 0.25, 0.75, 1e-8, 0.125, 3.875 / 1.8, 4.0], np.float32)
+
+    @settings(max_examples=int(os.environ.get("ZOIC_FUZZ_EXAMPLES_HOSTILE", os.environ.get("ZOIC_FUZZ_EXAMPLES", "80"))), deadline=None,
+              suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.sampled_from(lenses), st.sampled_from([RAYTRACED, RAYTRACED, THINLENS]), st.booleans(), st.booleans(), st.floats(2.0, 12.0, width=32),
+           st.floats(1.25, 11.0, width=32), st.floats(1.0, 7.5, width=32), st.floats(0.0, 4.0, width=32), st.integers(0, 2 ** 16), st.floats(0.1, 0.9))
+    def run(lens, model, lut, image, focal, fstop, sensor_w, ov, seed, share):
+        rs = np.random.RandomState(seed)
+        p = dict(lensModel=model, lensDataPath=lens_path(lens), focalLength=focal, fStop=fstop, focalDistance=100.0, sensorWidth=sensor_w,
+                 sensorHeight=sensor_w / 1.5, kolbSamplingLUT=lut, useImage=image, opticalVignettingDistance=ov, bokehPath="mem:hostile%d" % seed)
+        cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+        if image:
+            h, w = int(rs.randint(2, 40)), int(rs.randint(2, 40))
+            img = np.repeat(rs.rand(h, w).astype(np.float32)[:, :, None], 3, axis=2)
+            cam.set_bokeh_image(img); oc.set_bokeh_image(img)
+        try:
+            oc.update(**p)
+        except oracle_lib.OracleError:
+            return
+        cam.update(**p)
+        cam.set_seed(seed)
+        n = 4096
+        s, base = slab("C2", n, 0.5)
+        s = s.copy()
+        hostile = rs.rand(n, 4) < share * 0.5
+        s[hostile] = special[rs.randint(len(special), size=int(hostile.sum()))]
+        ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=seed, ray_index_base=base), threads=4)
+        got = cam.create_rays(s, ray_index_base=base)
+        assert np.array_equal(got["flags"], ref["flags"]), (p, np.nonzero(got["flags"] != ref["flags"])[0][:4], s[np.nonzero(got["flags"] != ref["flags"])[0][:4]])
+        g, r = got["planes"], ref["planes"]
+        same = (bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))
+        bad = np.nonzero(~same.all(0))[0]
+        assert same.all(), (p, len(bad), s[bad[:4]], g[:, bad[:4]], r[:, bad[:4]])
+        assert cam.counters() == oc.counters(), p
+    run()
+
+
 def test_perturbed_prescription_fuzz(gpu, oracle_lib):
     """Machine-made LENSES: a shipped prescription with every radius, thickness, index and aperture moved by up to
     +-25 %, sometimes with an element dropped or doubled (interface counts 5 ... 14: unrolled and rolled traces), behind
