@@ -61,6 +61,48 @@ def test_one_render_thread_replays_the_reference_process(gpu, oracle_lib):
     assert np.array_equal(bits(got2[:, 3:6].T.copy()), bits(ref2["dir"]))
 
 
+def test_per_sample_fuzz_replays_the_reference_process(gpu, oracle_lib):
+    """The per-sample call through the resident kernel (csrc/mailbox.hip: its own one-ray code path, not the batch kernels)
+    behind machine-made cameras: every shipped prescription with a stop, both lens models, LUT on / off, bokeh images that
+    are not square, some samples nobody should send.  240 calls from render thread 0 must equal the oracle's sequential
+    run (the process-global xor128 stream, advanced by the LUT build and by every retry in sample order), bit for bit."""
+    import os
+    from hypothesis import given, settings, HealthCheck, strategies as st
+    from zoic_amd import RAYTRACED, THINLENS, lens_path
+    lenses = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat", "triplet_f2.5.dat", "mori_f2.8.dat"]
+    special = np.array([0.0, -0.0, 0.5, 1.0, -1.0, 0.99999994, 1e-40, 1e30, np.inf, -np.inf, np.nan, 2.0, -3.0], np.float32)
+
+    @settings(max_examples=int(os.environ.get("ZOIC_FUZZ_EXAMPLES_SAMPLE", os.environ.get("ZOIC_FUZZ_EXAMPLES", "40"))), deadline=None,
+              suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.sampled_from(lenses), st.sampled_from([RAYTRACED, RAYTRACED, RAYTRACED, THINLENS]), st.booleans(), st.booleans(),
+           st.floats(2.0, 12.0, width=32), st.floats(1.25, 11.0, width=32), st.floats(1.0, 7.5, width=32), st.integers(0, 2 ** 16), st.floats(0.05, 0.95))
+    def run(lens, model, lut, image, focal, fstop, sensor_w, seed, where):
+        rs = np.random.RandomState(seed)
+        p = dict(lensModel=model, lensDataPath=lens_path(lens), focalLength=focal, fStop=fstop, focalDistance=100.0, sensorWidth=sensor_w,
+                 sensorHeight=sensor_w / 1.5, kolbSamplingLUT=lut, useImage=image, bokehPath="mem:persample%d" % seed)
+        cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+        if image:
+            h, w = int(rs.randint(2, 24)), int(rs.randint(2, 24))
+            img = np.repeat(rs.rand(h, w).astype(np.float32)[:, :, None], 3, axis=2)
+            cam.set_bokeh_image(img); oc.set_bokeh_image(img)
+        try:
+            oc.update(**p)
+        except oracle_lib.OracleError:
+            return
+        cam.update(**p)
+        n = 240
+        s, _ = _slab("C2", 8 * n, where)
+        s = s[::8].copy()
+        hostile = rs.rand(n, 4) < 0.02
+        s[hostile] = special[rs.randint(len(special), size=int(hostile.sum()))]
+        ref = oc.create_rays(s)               # rng_states=None: the sequential global stream
+        got = np.array([_out_tuple(cam.create_ray(*[float(v) for v in row], tid=0)) for row in s], np.float32)
+        for a, b in ((got[:, 0:3].T.copy(), ref["origin"]), (got[:, 3:6].T.copy(), ref["dir"]), (got[:, 6].copy(), ref["weight"])):
+            same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), (p, np.nonzero(~same)[-1][:4])
+    run()
+
+
 def test_mailbox_survives_idle_lifetime_mode_changes_and_shared_slots(gpu, oracle_lib):
     """The resident per-sample kernel (csrc/mailbox.hip) retires after 1 ms without a call and after 50 ms in any case, is
     stopped by set_precision / update / the counter getters, and serves tids 64 apart from ONE slot.  Whatever it does, the
