@@ -945,6 +945,11 @@ def test_bokeh_image_fuzz(gpu, oracle_lib):
         except oracle_lib.OracleError:
             return
         cam.update(**p)
+        ta, tb = cam.bokeh_tables(), oc.bokeh_tables()      # GPU CDF build (row sums, two descending sorts with ties, prefix sums)
+        for k in ("rowIndices", "columnIndices"):
+            assert np.array_equal(ta[k], tb[k]), (p, k)
+        for k in ("cdfRow", "cdfColumn"):
+            assert np.array_equal(bits(ta[k]), bits(tb[k])), (p, k)
         cam.set_seed(seed)
         n = 8192
         s, base = slab("C3", n, where)
