@@ -103,6 +103,84 @@ def test_per_sample_fuzz_replays_the_reference_process(gpu, oracle_lib):
     run()
 
 
+def test_update_sequence_fuzz(gpu, oracle_lib):
+    """node_update is stateful (zoic.cpp:1575-1720): the lens is rebuilt -- and the process-global xor128 stream advanced
+    by the LUT build's 6.4 M draws -- only when a lens parameter changed (1615, 1708-1710), the bokeh tables only when the
+    image switch or path did, and everything else is re-derived every time.  Random sequences of updates on ONE camera
+    (f-stop, focal length, focus, sensor, LUT / DOF / image / lens-model switches, another prescription, another image,
+    an update that changes nothing) against ONE oracle camera: after every step the exit-pupil LUT, a batch of rays (per-ray
+    streams) and a run of per-sample calls on render thread 0 (the global stream: it only stays in step if both sides
+    rebuilt -- or skipped -- the same things) must be bit-identical."""
+    import os
+    from hypothesis import given, settings, HealthCheck, strategies as st
+    from zoic_amd import RAYTRACED, THINLENS, lens_path
+    lenses = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat", "triplet_f2.5.dat", "mori_f2.8.dat"]
+    ops = ["fstop", "focal", "focus", "sensor", "lut", "model", "image", "newimage", "lens", "same", "exposure", "dof", "ov"]
+
+    @settings(max_examples=int(os.environ.get("ZOIC_FUZZ_EXAMPLES_UPDATE", os.environ.get("ZOIC_FUZZ_EXAMPLES", "25"))), deadline=None,
+              suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.integers(0, 2 ** 16), st.lists(st.sampled_from(ops), min_size=3, max_size=7))
+    def run(seed, steps):
+        rs = np.random.RandomState(seed)
+        cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+        images = [0]
+
+        def new_image():
+            images[0] += 1
+            h, w = int(rs.randint(2, 48)), int(rs.randint(2, 48))
+            img = np.repeat(rs.rand(h, w).astype(np.float32)[:, :, None], 3, axis=2)
+            cam.set_bokeh_image(img); oc.set_bokeh_image(img)
+            return "mem:seq%d_%d" % (seed, images[0])
+
+        p = dict(lensModel=RAYTRACED, lensDataPath=lens_path(lenses[rs.randint(len(lenses))]), focalLength=5.0, fStop=2.8, focalDistance=100.0,
+                 sensorWidth=3.6, sensorHeight=2.4, kolbSamplingLUT=True, useImage=False, bokehPath="", useDof=True, exposureControl=0.0,
+                 opticalVignettingDistance=0.0)
+        for step, op in enumerate(["first"] + list(steps)):
+            if op == "fstop": p["fStop"] = float(np.float32(rs.uniform(1.4, 11.0)))
+            elif op == "focal": p["focalLength"] = float(np.float32(rs.uniform(3.0, 10.0)))
+            elif op == "focus": p["focalDistance"] = float(np.float32(rs.uniform(30.0, 500.0)))
+            elif op == "sensor": p["sensorWidth"] = float(np.float32(rs.uniform(1.5, 5.0)))
+            elif op == "lut": p["kolbSamplingLUT"] = not p["kolbSamplingLUT"]
+            elif op == "model": p["lensModel"] = THINLENS if p["lensModel"] == RAYTRACED else RAYTRACED
+            elif op == "image":
+                p["useImage"] = not p["useImage"]
+                if p["useImage"] and not p["bokehPath"]:
+                    p["bokehPath"] = new_image()
+            elif op == "newimage":
+                p["bokehPath"] = new_image(); p["useImage"] = True
+            elif op == "lens": p["lensDataPath"] = lens_path(lenses[rs.randint(len(lenses))])
+            elif op == "exposure": p["exposureControl"] = float(np.float32(rs.uniform(-2.0, 2.0)))
+            elif op == "dof": p["useDof"] = not p["useDof"]
+            elif op == "ov": p["opticalVignettingDistance"] = float(np.float32(rs.uniform(0.0, 5.0)))
+            perr = oerr = None
+            try:
+                cam.update(**p)
+            except ZoicError as e:
+                perr = getattr(e, "status_name", type(e).__name__).replace("ZOIC_ERR_", "")
+            try:
+                oc.update(**p)
+            except oracle_lib.OracleError as e:
+                oerr = oracle_lib.ERR_NAMES[e.code]
+            assert perr == oerr, (step, op, p, perr, oerr)
+            if perr is not None:
+                return
+            if p["lensModel"] == RAYTRACED and p["kolbSamplingLUT"]:
+                assert np.array_equal(bits(cam.info()["lutBoxes"]), bits(oc.lut()[1])), (step, op, p)
+            n = 2048
+            s, base = _slab("C2", n, float(rs.uniform(0.05, 0.95)))
+            ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=1, ray_index_base=base), threads=4)
+            got = cam.create_rays(s, ray_index_base=base)
+            assert np.array_equal(got["flags"], ref["flags"]), (step, op, p)
+            g, r = got["planes"], ref["planes"]
+            assert ((bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))).all(), (step, op, p)
+            t = s[::64][:32]
+            seq = oc.create_rays(t)            # the sequential global stream
+            one = np.array([_out_tuple(cam.create_ray(*[float(v) for v in row], tid=0)) for row in t], np.float32)
+            for a, b in ((one[:, 0:3].T.copy(), seq["origin"]), (one[:, 3:6].T.copy(), seq["dir"]), (one[:, 6].copy(), seq["weight"])):
+                assert ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all(), (step, op, p)
+    run()
+
+
 def test_mailbox_survives_idle_lifetime_mode_changes_and_shared_slots(gpu, oracle_lib):
     """The resident per-sample kernel (csrc/mailbox.hip) retires after 1 ms without a call and after 50 ms in any case, is
     stopped by set_precision / update / the counter getters, and serves tids 64 apart from ONE slot.  Whatever it does, the
