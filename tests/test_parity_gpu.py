@@ -775,6 +775,15 @@ def test_hostile_sample_fuzz(gpu, oracle_lib):
         bad = np.nonzero(~same.all(0))[0]
         assert same.all(), (p, len(bad), s[bad[:4]], g[:, bad[:4]], r[:, bad[:4]])
         assert cam.counters() == oc.counters(), p
+        # the fast mode on the same batch: it must come back, every ray with a legal try count, and the ordinary samples of
+        # the batch decided as the oracle decides them (hostile ones: NaN-ness of the direction as the oracle's)
+        cam.set_precision(PRECISION_FAST)
+        fast = cam.create_rays(s, ray_index_base=base)
+        assert (fast["tries"] <= 26).all(), p
+        plain = ~hostile.any(1)
+        if plain.sum() > 200:
+            assert float((fast["flags"][plain] != ref["flags"][plain]).mean()) < 40 * FLIP_TOL, p     # ~2000 rays: one flip is 5e-4
+        assert np.array_equal(np.isnan(fast["dir"]).any(0), np.isnan(ref["dir"]).any(0)) or (fast["flags"] != ref["flags"]).any(), p
     run()
 
 
