@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of one repetition of a CPU baseline leg")
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="N > 1: seconds the ShardedFrame section may take before the line is printed without it")
     ap.add_argument("--gather-chunk-mb", type=int, default=0, help="payload MB per gather chunk (0: a quarter of a slab, at least 64 MB)")
     return ap.parse_args()
 
@@ -458,11 +459,33 @@ def main():
         line["configs"] = ents
 
     if not args.no_sharded:
+        # The RCCL gather of ShardedFrame has never run with peers (one GPU per lease): with more than one rank a
+        # watchdog keeps a hang in it from taking the headline (measured above, without any collective) down with it.
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    line["sharded_frame"] = "timed out after %d s (RCCL gather with peers)" % args.sharded_timeout
+                    line["notes"] = NOTES
+                    print(json.dumps(line, separators=(",", ":")), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(args.sharded_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         sh = []
-        for cname, st in (("C4", 5), ("C5", 2)):
-            e = sharded_frame_entry(torch, dist, cname, dev, rank, world, local_rank, st, args.gather_chunk_mb)
-            if rank == 0:
-                sh.append(e)
+        try:
+            for cname, st in (("C4", 5), ("C5", 2)):
+                e = sharded_frame_entry(torch, dist, cname, dev, rank, world, local_rank, st, args.gather_chunk_mb)
+                if rank == 0:
+                    sh.append(e)
+        except Exception as e:   # the headline must survive a failure of the gather experiment
+            if world == 1:
+                raise
+            sh.append("failed: %s" % (str(e)[:200],))
+        if watchdog is not None:
+            watchdog.cancel()
         if rank == 0:
             line["sharded_frame"] = sh
 
