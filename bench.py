@@ -469,6 +469,8 @@ def main():
                 if rank == 0:
                     line["sharded_frame"] = "timed out after %d s (RCCL gather with peers)" % args.sharded_timeout
                     line["notes"] = NOTES
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
                     print(json.dumps(line, separators=(",", ":")), flush=True)
                 os._exit(0)
             watchdog = threading.Timer(args.sharded_timeout, give_up)
@@ -489,6 +491,11 @@ def main():
         if rank == 0:
             line["sharded_frame"] = sh
 
+    if dist:   # whatever the ranks' C libraries still hold (RCCL's banner) leaves before the line, so that the line comes last
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        dist.barrier(device_ids=[local_rank])
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
@@ -497,6 +504,9 @@ def main():
         if len(text) > 6000:     # the driver keeps the tail of the line: what explains goes first, the numbers stay
             del line["notes"]
             text = json.dumps(line, separators=(",", ":"))
+        if dist:   # RCCL prints its version banner through C stdio (block-buffered on a pipe): out with it before the line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         print(text, flush=True)
     if dist:
         dist.barrier(device_ids=[local_rank])
