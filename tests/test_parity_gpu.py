@@ -775,6 +775,17 @@ def test_hostile_sample_fuzz(gpu, oracle_lib):
         bad = np.nonzero(~same.all(0))[0]
         assert same.all(), (p, len(bad), s[bad[:4]], g[:, bad[:4]], r[:, bad[:4]])
         assert cam.counters() == oc.counters(), p
+        # the same batch through the Arnold-layout entry point (28-byte AtCameraInput rows in, 84-byte AtCameraOutput rows out,
+        # expanded on the GPU): origin / dir / weight as above, dOdy = origin and dDdy = dir for retried rays only (zoic.cpp:1974-1977)
+        inp = np.zeros((n, 7), np.float32)
+        inp[:, 0], inp[:, 1], inp[:, 4], inp[:, 5] = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
+        out = cam.create_rays_arnold(inp, ray_index_base=base)
+        eq = lambda a, b: ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()   # noqa: E731
+        assert eq(out[:, 0:3].T.copy(), ref["origin"]) and eq(out[:, 3:6].T.copy(), ref["dir"]), p
+        assert eq(out[:, 18].copy(), ref["weight"]) and eq(out[:, 20].copy(), ref["weight"]), p
+        retried = (ref["flags"] & 1) != 0
+        assert eq(out[retried, 9:12].copy(), out[retried, 0:3].copy()) and eq(out[retried, 15:18].copy(), out[retried, 3:6].copy()), p
+        assert not out[~retried, 9:12].any() and not out[~retried, 15:18].any() and not out[:, 6:9].any() and not out[:, 12:15].any(), p
         # the fast mode on the same batch: it must come back, every ray with a legal try count, and the ordinary samples of
         # the batch decided as the oracle decides them (hostile ones: NaN-ness of the direction as the oracle's)
         cam.set_precision(PRECISION_FAST)

@@ -38,8 +38,9 @@ __device__ __forceinline__ bool vignet_pass(const ThinTable &T, V3 origin, V3 di
 }
 
 // FAST (zoic_camera_set_precision): f32 rsq normalisation, the f32 disk mapping and v_sqrt in the vignetting test instead
-// of the reference's correctly rounded divides and square roots -- ~75 instead of ~140 instructions per redraw; direction
-// error ~1e-7, decision flips at the vignetting boundary only (tests/test_parity_gpu.py).  STRICT is bit-exact.
+// of the reference's correctly rounded divides and square roots -- ~80 instead of ~140 instructions per redraw; direction
+// error ~1e-7; a vignetting test within a few ulps of its limit is re-taken in the reference's arithmetic (decision-safe, like
+// the Kolb kernels' guard band).  STRICT is bit-exact.
 template <bool FAST>
 __global__ __launch_bounds__(kThinBlock) void thin_refill_kernel(const ThinTable T, const BokehTables B, const float4 *__restrict__ samples,
                                                                  const uint4 *__restrict__ rngStates, uint64_t rayBase, uint32_t n,
@@ -124,15 +125,29 @@ __global__ __launch_bounds__(kThinBlock) void thin_refill_kernel(const ThinTable
                                                : bokeh_sample_device(B, T.bokehW, T.bokehH, u, v))
                                    : (FAST ? concentric_disk_f32(u, v) : concentric_disk(u, v));
                 lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
-                const V3 origin{lens.x, lens.y, 0.0f};
+                V3 origin{lens.x, lens.y, 0.0f};
                 V3 dir;
                 bool clear;
                 if constexpr (FAST) {
                     const V3 q{fpx - origin.x, fpy - origin.y, fpz - origin.z};
                     const float inv = frsq_fast(q.x * q.x + q.y * q.y + q.z * q.z);
                     dir = V3{q.x * inv, q.y * inv, q.z * inv};
-                    const float px = dir.x * T.ovDistance - origin.x, py = dir.y * T.ovDistance - origin.y;
-                    clear = fsqrt_fast(px * px + py * py) < T.apertureRadius * T.ovRadius;
+                    const float ax = dir.x * T.ovDistance, ay = dir.y * T.ovDistance;
+                    const float px = ax - origin.x, py = ay - origin.y;
+                    const float hyp = fsqrt_fast(px * px + py * py), lim = T.apertureRadius * T.ovRadius;
+                    clear = hyp < lim;
+                    // Decision-safe: the f32 shortcuts above are good to a few ulps of the terms of p; a test that close to the
+                    // limit is re-taken in the reference's arithmetic, lens sample included (rare and divergent -- except on
+                    // degenerate settings such as a vignetting distance of ~0 behind an image whose rim pixels sit ON the limit).
+                    if (fabsf(hyp - lim) <= 2.0e-6f * (fabsf(ax) + fabsf(ay) + fabsf(origin.x) + fabsf(origin.y))) {
+                        V2 ls = useImage ? (rowCells ? bokeh_sample_cells<true>(B, rowCells, T.bokehW, T.bokehH, u, v)
+                                                     : bokeh_sample_device(B, T.bokehW, T.bokehH, u, v))
+                                         : concentric_disk(u, v);
+                        ls.x *= T.apertureRadius; ls.y *= T.apertureRadius;
+                        origin = V3{ls.x, ls.y, 0.0f};
+                        dir = normalize3(V3{fpx - origin.x, fpy - origin.y, fpz - origin.z});
+                        clear = vignet_pass(T, origin, dir);
+                    }
                 } else {
                     dir = normalize3(V3{fpx - origin.x, fpy - origin.y, fpz - origin.z});
                     clear = vignet_pass(T, origin, dir);
