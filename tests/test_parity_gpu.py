@@ -732,6 +732,59 @@ def test_fast_parameter_fuzz(gpu, oracle_lib):
     assert worst["strictOnly"] * 4 <= worst["cameras"]     # the shipped prescriptions are inside the domain but for odd focus settings
 
 
+def test_wild_parameter_fuzz(gpu, oracle_lib):
+    """Parameters far outside the UI's ranges (zoic.mtd) -- the reference checks none of them: focal lengths 0.2 ... 100,
+    f-stops 0.3 ... 64, focus distances from inside the lens to 1e5, sensors 0.1 ... 12 wide, vignetting radii 0.1 ... 3,
+    now and then a zero or a negative number.  Whatever node_update makes of them (negative apertures, NaN tables, a LUT
+    of zeros) and whatever the rays then do, strict mode is bit-identical to the oracle, counters and error class included;
+    the fast mode comes back with legal try counts."""
+    from hypothesis import given, settings, HealthCheck, strategies as st
+    lenses = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat", "triplet_f2.5.dat", "mori_f2.8.dat"]
+    odd = st.sampled_from([0.0, -1.0, -5.0, 1e-6, 1e6])
+
+    def wide(lo, hi):
+        return st.one_of(st.floats(lo, hi, width=32), st.floats(lo, hi, width=32), st.floats(lo, hi, width=32), odd)
+
+    @settings(max_examples=int(os.environ.get("ZOIC_FUZZ_EXAMPLES_WILD", os.environ.get("ZOIC_FUZZ_EXAMPLES", "100"))), deadline=None,
+              suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.sampled_from(lenses), wide(0.25, 100.0), wide(0.3125, 64.0), wide(1.0, 1e5), wide(0.125, 12.0), wide(0.125, 3.0), wide(0.0, 50.0),
+           st.floats(-6.0, 6.0, width=32), st.booleans(), st.booleans(), st.sampled_from([RAYTRACED, RAYTRACED, THINLENS]), st.floats(0.02, 0.98),
+           st.integers(0, 2 ** 20))
+    def run(lens, focal, fstop, focus, sensor_w, ovr, ov, exposure, lut, dof, model, where, seed):
+        p = dict(lensModel=model, lensDataPath=lens_path(lens), focalLength=focal, fStop=fstop, focalDistance=focus, sensorWidth=sensor_w,
+                 sensorHeight=sensor_w / 1.5, exposureControl=exposure, kolbSamplingLUT=lut, useDof=dof, opticalVignettingDistance=ov,
+                 opticalVignettingRadius=ovr, useImage=False)
+        cam, oc = ZoicCamera(0), oracle_lib.OracleCamera()
+        perr = oerr = None
+        try:
+            cam.update(**p)
+        except Exception as e:
+            perr = getattr(e, "status_name", type(e).__name__).replace("ZOIC_ERR_", "")
+        try:
+            oc.update(**p)
+        except oracle_lib.OracleError as e:
+            oerr = oracle_lib.ERR_NAMES[e.code]
+        assert perr == oerr, (p, perr, oerr)
+        if perr is not None:
+            return
+        if model == RAYTRACED and lut:
+            assert np.array_equal(bits(cam.info()["lutBoxes"]), bits(oc.lut()[1])), p
+        cam.set_seed(seed)
+        n = 4096
+        s, base = slab("C2", n, where)
+        ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=seed, ray_index_base=base), threads=4)
+        got = cam.create_rays(s, ray_index_base=base)
+        assert np.array_equal(got["flags"], ref["flags"]), p
+        g, r = got["planes"], ref["planes"]
+        same = (bits(g) == bits(r)) | (np.isnan(g) & np.isnan(r))
+        assert same.all(), (p, int((~same.all(0)).sum()))
+        assert cam.counters() == oc.counters(), p
+        cam.set_precision(PRECISION_FAST)
+        fast = cam.create_rays(s, ray_index_base=base)
+        assert (fast["tries"] <= 26).all(), p
+    run()
+
+
 def test_hostile_sample_fuzz(gpu, oracle_lib):
     """Samples nobody should send, through cameras of every kind (both lens models, LUT on / off, bokeh image on / off, every
     shipped prescription with a stop): zeros of both signs, 0.5 (the disk mapping's 0/0), 1.0 and its neighbours, negative
