@@ -32,6 +32,8 @@ for cfg in a.configs.split(","):
         lib.zoic_debug_region_cycles(rc, 1)
         tot = float(sum(rc)) or 1.0
         names = ["top/flush", "setup_ray", "first try", "pool pop", "retry search", "advance", "trace", "finish+store", "push", "tail"]
+        print("   tail: %.1f %% of the wave time is passes without fresh work (drain)" % (100.0 * rc[9] / max(tot - rc[9], 1.0)))
+        tot -= rc[9]
         print("   wave-time shares: " + ", ".join("%s %.1f%%" % (names[i], 100.0 * rc[i] / tot) for i in range(9)))
         print("%s %-9s rays %d: per 64 rays: A %.3f B %.3f passes, search iterations %.3f (looking %.1f lanes each), traces %.3f (cand %.1f lanes each), active lanes/pass %.1f, finished %d" % (
             cfg, mode, n, A * 64 / n, B * 64 / n, it * 64 / n, look / max(it, 1), tr * 64 / n, candl / max(tr, 1), act / max(A + B, 1), fin))

@@ -423,6 +423,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     ZOIC_PS_DECL
     for (;;) {
         const bool drain = !have1;                                          // no fresh sample left for this wave
+#ifdef ZOIC_PASS_STATS
+        const unsigned long long drainT0 = __builtin_readcyclecounter();
+#endif
         const bool fromPool = poolCnt >= 64u || (drain && poolCnt != 0u);
         if (!fromPool && drain) break;
         ZOIC_PS_ADD(fromPool ? 1 : 0, 1)
@@ -713,6 +716,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             }
         }
         ZOIC_MARK(8)   // hand-overs + pool push
+#ifdef ZOIC_PASS_STATS
+        if (drain) rt[9] += __builtin_readcyclecounter() - drainT0;   // [9]: the whole of every pass run without fresh work (the wave's tail)
+#endif
         // ---- hand-over lists: emptied in whole batches ---------------------------------------------------------------------
         if constexpr (GUARD) {
             if (unsureCnt >= 64u) {   // one atomic reserves exactly the entries written: no holes in the work list
