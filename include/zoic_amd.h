@@ -70,7 +70,10 @@ typedef enum zoic_precision {
        computation puts the sensor in FRONT of the rear vertex (originShift >= lenses[0].thickness) sends its rays away from
        the lens: the reference's one signed root (zoic.cpp:986, t < 0 never rejected) then lands far behind the ray, and the
        hit-point rounding no longer is small against the radii.  Such a camera (zoic_lens_info::fastRunsStrict) runs STRICT in
-       every mode. */
+       every mode.  So does a camera that fails zoic_camera_update's self-check: 4096 probe samples spread over the frame go
+       through the STRICT and the decision-safe FAST kernels, and the FAST modes are kept only if at most one of them is
+       decided differently and the direction RMSE of the others is < 1e-5 (0.3 ms per update; no counter, no retry stream is
+       touched). */
 } zoic_precision;
 
 #define ZOIC_MAX_LENS_SURFACES 32

@@ -924,7 +924,9 @@ def test_perturbed_prescription_fuzz(gpu, oracle_lib):
         assert cam.counters() == oc.counters(), (text, kw)
         strictOnly = cam.info()["fastRunsStrict"]     # negative focal-length ratio or the sensor in front of the rear vertex: outside the FAST modes' domain (zoic_amd.h)
         i = cam.info()
-        assert strictOnly == (not (i["focalLengthRatio"] > 0 and i["originShift"] < i["elements"][0, 1])), (text, kw)
+        geometric = not (i["focalLengthRatio"] > 0 and i["originShift"] < i["elements"][0, 1])
+        assert strictOnly or not geometric, (text, kw)      # the rest of strictOnly: node_update's self-check of the fast modes said no
+        tally["selfCheck"] += bool(strictOnly and not geometric)
         tally["strictOnly"] += strictOnly
         cam.set_precision(PRECISION_FAST)
         fast = cam.create_rays(s, ray_index_base=base)
@@ -936,17 +938,17 @@ def test_perturbed_prescription_fuzz(gpu, oracle_lib):
         if live.sum() > 100:
             dd = fast["dir"][:, live].astype(np.float64) - ref["dir"][:, live]
             rmse = float(np.sqrt((dd ** 2).sum(0).mean()))
-            # 1e-5 is north_star's figure for the shipped prescriptions (test_fast_parameter_fuzz holds it on all of them).  A
-            # machine-made lens can be far worse conditioned: FAST takes cos(i) from thc = sqrt(R^2 - d2) instead of a dot
-            # product (fast_optics.hpp), and a grazing hit on a strongly curved element cancels in R^2 - d2 -- 6e-5 on a
-            # fisheye with an element removed.  A sanity bound here; the worst case and the share above 1e-5 are printed.
-            assert rmse < 3.0e-4, (text, kw, rmse)
+            # 1e-5 is north_star's figure; node_update's self-check (capi.cpp fast_self_check) holds every camera to it on its
+            # own 4096 probe rays and sends the others to STRICT (machine-made lenses can be badly conditioned: FAST takes
+            # cos(i) from thc = sqrt(R^2 - d2), which cancels at grazing incidence -- 6e-5 on a fisheye with an element
+            # removed).  This slab is another sample of the frame: three times the figure, worst case printed.
+            assert rmse < 3 * DIR_RMSE_TOL, (text, kw, rmse)
             tally["rmse"] = max(tally["rmse"], rmse)
             tally["above"] += rmse >= DIR_RMSE_TOL
-    tally = dict(rejected=0, compared=0, alive=0.0, retried=0.0, counts=set(), rmse=0.0, above=0, strictOnly=0)
+    tally = dict(rejected=0, compared=0, alive=0.0, retried=0.0, counts=set(), rmse=0.0, above=0, strictOnly=0, selfCheck=0)
     run()
-    print("lens fuzz: %d cameras compared (%d rejected alike), mean live fraction %.2f, mean retried fraction %.2f, interface counts %s, worst fast-mode direction RMSE %.3g (%d cameras at or above 1e-5), %d cameras outside the fast modes' domain"
-          % (tally["compared"], tally["rejected"], tally["alive"] / max(tally["compared"], 1), tally["retried"] / max(tally["compared"], 1), sorted(tally["counts"]), tally["rmse"], tally["above"], tally["strictOnly"]))
+    print("lens fuzz: %d cameras compared (%d rejected alike), mean live fraction %.2f, mean retried fraction %.2f, interface counts %s, worst fast-mode direction RMSE %.3g (%d cameras at or above 1e-5), %d cameras outside the fast modes' domain (%d of them by node_update's self-check)"
+          % (tally["compared"], tally["rejected"], tally["alive"] / max(tally["compared"], 1), tally["retried"] / max(tally["compared"], 1), sorted(tally["counts"]), tally["rmse"], tally["above"], tally["strictOnly"], tally["selfCheck"]))
     assert tally["compared"] >= 10
 
 

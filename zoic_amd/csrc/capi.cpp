@@ -261,6 +261,9 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     BokehTables bokehDev{};
     DeviceCounters *dCounters = nullptr;
     DeviceBuffer<float> dProbeU, dProbeV;   // node_update scratch (single-threaded by contract)
+    DeviceBuffer<float> dFastProbe;         // fast_self_check: its samples ...
+    DeviceBuffer<RayRecord> dFastProbeRays; // ... and the STRICT + FAST records of them
+    bool fastProbeReady = false;
     DeviceBuffer<uint8_t> dProbeOk;
     unsigned int *dProbeTir = nullptr;
     // ---- concurrent ray calls (see the threading note at the top of this file)
@@ -561,14 +564,17 @@ zoic_status check_ray_call(const zoic_camera *cam)
 }
 
 // One launch of camera_create_ray over n samples on `stream`, asynchronous.  Safe to call from many host threads at once.
+// modeOverride (0 STRICT / 1 decision-safe FAST / 2 unchecked; -1: the camera's) and counted = false (no counter is touched)
+// serve node_update's self-check of the FAST modes.
 zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, const uint32_t *d_rng, uint64_t rayBase, RayRecord *d_rays,
-                        hipStream_t stream)
+                        hipStream_t stream, int modeOverride = -1, bool counted = true)
 {
     static_assert(sizeof(zoic_ray) == sizeof(RayRecord), "zoic_ray layout");
     const int model = cam->params.p.lensModel;
     if (model != ZOIC_RAYTRACED && model != ZOIC_THINLENS)
         return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
-    const int mode = cam->kernel_mode();
+    const int mode = modeOverride >= 0 ? modeOverride : cam->kernel_mode();
+    DeviceCounters *const dCounters = counted ? cam->dCounters : nullptr;
     // the Kolb launch's scratch (kernels.hpp): decision-safe FAST's work list, the finish kernel's byte map
     const size_t listEntries = model == ZOIC_RAYTRACED ? kolb_scratch_dwords(cam->kolb, n, mode) : 0;
     const bool needList = listEntries != 0;
@@ -604,11 +610,11 @@ zoic_status launch_rays(zoic_camera *cam, uint64_t n, const float *d_samples, co
             ZOIC_HIP(hipMemsetAsync(slot->cursor, 0, 2 * kCursorStride * sizeof(unsigned int), stream));
             slot->cursorsDirty = false;
         }
-        rc = launch_kolb_rays(cam->kolb, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, &slot->parity, mode,
+        rc = launch_kolb_rays(cam->kolb, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, dCounters, slot->cursor, &slot->parity, mode,
                               needList ? slot->redo.ptr : nullptr, stream);
         if (rc != 0) slot->cursorsDirty = true;
     } else {
-        rc = launch_thin_rays(cam->thin, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, cam->dCounters, slot->cursor, mode != 0, stream);
+        rc = launch_thin_rays(cam->thin, cam->bokehDev, d_samples, d_rng, rayBase, n, d_rays, dCounters, slot->cursor, mode != 0, stream);
         slot->cursorsDirty = true;   // the thin-lens kernels reset the block they use themselves and leave it used
     }
     // whatever the launcher returned, part of the launch (cursor reset, the first kernel) may be queued: the slot's next user
@@ -639,6 +645,48 @@ inline void expand_record(const zoic_ray &r, zoic_camera_output &o)
     if (w == 0.0f) o.weight[0] = o.weight[1] = o.weight[2] = 0.0f;  // output.weight = 0.0f, zoic.cpp:1825/1952
     else if (w != 1.0f) { o.weight[0] *= w; o.weight[1] *= w; o.weight[2] *= w; }  // exposure factor
     if (r.flags & 1u) { o.dOdy = o.origin; o.dDdy = o.dir; }  // zoic.cpp:1974-1977
+}
+
+// node_update's self-check of the FAST modes (RAYTRACED): kFastProbeRays samples spread over the frame go through the STRICT and
+// the decision-safe FAST kernels; the camera keeps its FAST modes only if FAST decides these rays as STRICT does (one flip at
+// most) and its directions are within north_star's tolerance (RMSE < 1e-5 over the rays with weight).  FAST drops the
+// reference's renormalisations and takes cos(i) from the hit's geometry (fast_optics.hpp): exact on a lens laid out like a
+// lens, not on every table of numbers -- a prescription whose elements graze (a fisheye with an element removed: 6e-5) runs
+// STRICT instead.  No counter is touched, no retry stream advanced (per-ray streams of the probe's own ray indices).
+constexpr uint32_t kFastProbeRays = 4096;
+bool fast_self_check(zoic_camera *cam)
+{
+    if (cam->dFastProbe.reserve(kFastProbeRays * 4) != hipSuccess || cam->dFastProbeRays.reserve(2 * kFastProbeRays) != hipSuccess) return false;
+    if (!cam->fastProbeReady) {
+        std::vector<float> h(kFastProbeRays * 4);
+        for (uint32_t i = 0; i < kFastProbeRays; ++i) {   // a jittered 64 x 64 lattice over sx in [-1, 1], sy in [-2/3, 2/3]
+            const auto u01 = [](uint32_t v) { return static_cast<float>(pcg_hash(v) >> 8) * (1.0f / 16777216.0f); };
+            h[4 * i + 0] = ((static_cast<float>(i & 63u) + u01(4 * i)) / 64.0f) * 2.0f - 1.0f;
+            h[4 * i + 1] = (((static_cast<float>(i >> 6) + u01(4 * i + 1)) / 64.0f) * 2.0f - 1.0f) * (2.0f / 3.0f);
+            h[4 * i + 2] = u01(4 * i + 2);
+            h[4 * i + 3] = u01(4 * i + 3);
+        }
+        if (hipMemcpy(cam->dFastProbe.ptr, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
+        cam->fastProbeReady = true;
+    }
+    RayRecord *d = cam->dFastProbeRays.ptr;
+    if (launch_rays(cam, kFastProbeRays, cam->dFastProbe.ptr, nullptr, 0, d, nullptr, 0, false) != ZOIC_OK) return false;
+    if (launch_rays(cam, kFastProbeRays, cam->dFastProbe.ptr, nullptr, 0, d + kFastProbeRays, nullptr, 1, false) != ZOIC_OK) return false;
+    std::vector<RayRecord> r(2 * kFastProbeRays);
+    if (hipMemcpy(r.data(), d, r.size() * sizeof(RayRecord), hipMemcpyDeviceToHost) != hipSuccess) return false;   // orders behind the null stream
+    uint32_t flips = 0, live = 0;
+    double sum = 0.0;
+    for (uint32_t i = 0; i < kFastProbeRays; ++i) {
+        const RayRecord &a = r[i], &b = r[kFastProbeRays + i];
+        if (a.flags != b.flags) { ++flips; continue; }
+        if (a.weight == 0.0f || !std::isfinite(a.dx) || !std::isfinite(a.dy) || !std::isfinite(a.dz)) continue;
+        const double ex = static_cast<double>(a.dx) - b.dx, ey = static_cast<double>(a.dy) - b.dy, ez = static_cast<double>(a.dz) - b.dz;
+        const double e2 = ex * ex + ey * ey + ez * ez;
+        if (!(e2 == e2)) return false;   // FAST made a NaN where STRICT has a direction
+        sum += e2;
+        ++live;
+    }
+    return flips <= 1u && (live == 0u || std::sqrt(sum / live) < 1.0e-5);
 }
 
 }  // namespace
@@ -756,7 +804,7 @@ void zoic_camera_destroy(zoic_camera *cam)
             cam->slots[i].redo.release();
         }
         cam->dCdfRow.release(); cam->dCdfColumn.release(); cam->dRowIdx.release(); cam->dColIdx.release(); cam->dPyramid.release(); cam->dBokehCells.release();
-        cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release();
+        cam->dProbeU.release(); cam->dProbeV.release(); cam->dProbeOk.release(); cam->dFastProbe.release(); cam->dFastProbeRays.release();
         if (cam->dProbeTir) (void)hipFree(cam->dProbeTir);
         if (cam->dCounters) (void)hipFree(cam->dCounters);
         if (cam->dWorkCursor) (void)hipFree(cam->dWorkCursor);
@@ -933,6 +981,8 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
         t.seed = cam->seed;
     }
     cam->updated = true;
+    // the FAST modes are kept only for a camera they are good for (fast_self_check above; the geometric test comes first)
+    if (p->lensModel == ZOIC_RAYTRACED && cam->device != ZOIC_DEVICE_NONE && cam->fastDomain) cam->fastDomain = fast_self_check(cam);
     return ZOIC_OK;
 }
 
