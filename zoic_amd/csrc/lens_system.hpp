@@ -39,6 +39,9 @@ constexpr float kGuardScale = ZOIC_GUARD_SCALE;
 #endif
 constexpr double kRetryDeadMinShare = ZOIC_RETRY_DEAD_MIN_SHARE;
 constexpr float kGuardMinRelBand = 2.0e-5f;
+#ifndef ZOIC_GUARD_ALL
+#define ZOIC_GUARD_ALL 1   // every interface carries its band (0: only those whose estimate exceeds kGuardMinRelBand, round 2)
+#endif
 
 
 struct LutBox { float maxX = 0, maxY = 0, minX = 0, minY = 0; };  // boundingBox2d, zoic.cpp:490-493
