@@ -56,11 +56,11 @@ typedef enum zoic_lens_model { ZOIC_THINLENS = 0, ZOIC_RAYTRACED = 1, ZOIC_LENS_
 typedef enum zoic_precision {
     ZOIC_PRECISION_STRICT = 0, /* the reference's operation order, no FMA contraction, its f64 intermediates: bit-exact vs the CPU oracle */
     ZOIC_PRECISION_FAST = 1,   /* same algorithm, f32 only, FMA/rsq, redundant normalisations removed: direction RMSE < 1e-5.
-                                  Decision-safe: accept/reject decisions at ill-conditioned interfaces (in practice the stop, which
-                                  the reference traces as a sphere of |R| ~ 1e4 cm) that lie inside their guard band, and the
+                                  Decision-safe: housing / stop clips that lie inside the interface's guard band (wide at the stop,
+                                  which the reference traces as a sphere of |R| ~ 1e4 cm; a few ulps elsewhere), and the
                                   exit-pupil LUT's edge, are re-taken in STRICT arithmetic (a second kernel over the few rays
-                                  concerned).  Sphere-miss, TIR and well-conditioned clips are not guarded: residual flips of try
-                                  count / weight <= ~1e-6 of the rays (tests hold 5e-5); origin / direction differ in low-order bits */
+                                  concerned).  Sphere-miss and TIR decisions are not guarded: residual flips of try count /
+                                  weight <= ~3e-7 of the rays (tests hold 5e-5); origin / direction differ in low-order bits */
     ZOIC_PRECISION_FAST_UNCHECKED = 2 /* FAST without the decision check (A/B; decisions flip where the reference's own f32
                                          rounding noise decides, ~1e-5 ... 1e-3 of the rays depending on the lens) */
     /* Domain of the FAST modes: they drop the reference's per-interface renormalisations (the refracted direction stays unit
