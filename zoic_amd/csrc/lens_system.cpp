@@ -230,7 +230,7 @@ void LensSystem::fill_surfaces(KolbTable &t) const
     // point is only good to ~ulp(|R|) ~ 1e-3 cm, and the clip h^2 > r_stop^2 is decided by rounding for rays within
     // eps*|R|/r_stop (1e-4 ... 5e-3, relative) of the edge.  Measured (tools/flip_analysis.py, 8.4 M rays per config): every
     // FAST/STRICT disagreement but ~1e-7 of the rays is decided at the stop, with relative margins up to 0.9 x eps*|R|/r_stop.
-    // Every interface carries a band of kGuardScale times its estimate (8 eps at least): the well-conditioned ones sit at ~1e-6
+    // Every interface carries a band of kGuardScale times its estimate (kGuardFloorRel at least): the well-conditioned ones sit at ~1e-6
     // and cost a few more listed rays for half of the residual flips (16 M rays per config: C2 3 -> 1, C3 7 -> 4, C5 3 -> 1;
     // the two compares are in the kernel anyway).  Round 2 guarded only estimates above kGuardMinRelBand (-DZOIC_GUARD_ALL=0);
     // -DZOIC_GUARD_SCALE=x for experiments.
@@ -266,7 +266,7 @@ void LensSystem::fill_surfaces(KolbTable &t) const
         q.krScale = static_cast<float>(eta / (std::fabs(R) * R));
         const float relBand = eps * std::fabs(r.radius) / std::sqrt(s.housing2);   // relative to housing2
 #if ZOIC_GUARD_ALL
-        const float relAll = guardScale * relBand > 8.0f * eps ? guardScale * relBand : 8.0f * eps;
+        const float relAll = guardScale * relBand > kGuardFloorRel ? guardScale * relBand : kGuardFloorRel;
         const float band = (guardScale > 0.0f) ? relAll * s.housing2 : 0.0f;
 #else
         const float band = (relBand > kGuardMinRelBand) ? guardScale * relBand * s.housing2 : 0.0f;

@@ -39,6 +39,12 @@ constexpr float kGuardScale = ZOIC_GUARD_SCALE;
 #endif
 constexpr double kRetryDeadMinShare = ZOIC_RETRY_DEAD_MIN_SHARE;
 constexpr float kGuardMinRelBand = 2.0e-5f;
+// smallest band of an interface, relative to housing^2: FAST's error at the front elements is what it accumulated on the way
+// (measured: flips at well-conditioned interfaces with margins up to 1.5e-6, tools/flip_analysis.py on 33 M rays per config)
+#ifndef ZOIC_GUARD_FLOOR
+#define ZOIC_GUARD_FLOOR 3.8e-6f   // 64 eps
+#endif
+constexpr float kGuardFloorRel = ZOIC_GUARD_FLOOR;
 #ifndef ZOIC_GUARD_ALL
 #define ZOIC_GUARD_ALL 1   // every interface carries its band (0: only those whose estimate exceeds kGuardMinRelBand, round 2)
 #endif
