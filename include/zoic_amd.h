@@ -32,7 +32,15 @@
 extern "C" {
 #endif
 
-#define ZOIC_AMD_ABI_VERSION 2
+/* ABI history (a plug-in shim checks zoic_abi_version() == ZOIC_AMD_ABI_VERSION at load and refuses anything else):
+ *   1  round 1.
+ *   2  round 2: zoic_create_rays_arnold, zoic_host_*, per-tid retry streams.
+ *   3  round 3/4: zoic_lens_info gained the trailing fastRunsStrict (zoic_camera_get_info writes sizeof(zoic_lens_info) bytes:
+ *      a v2 caller's struct is 4 bytes short); zoic_create_rays_arnold WRITES EVERY OUTPUT ROW WHOLE (v2 updated fields in
+ *      place); zoic_camera_create_ray runs through a resident kernel, so a caller's hipDeviceSynchronize / hipFree can wait up
+ *      to 50 ms for it to retire (zoic_camera_get_counters / _update / _destroy stop it first); the zoic_frame_* entry points
+ *      (one frame over several devices of this process). */
+#define ZOIC_AMD_ABI_VERSION 3
 
 typedef enum zoic_status {
     ZOIC_OK = 0,
@@ -192,7 +200,13 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
  * without a call and is started again by the next one).  Re-entrant: every tid owns a retry stream that carries over from call
  * to call, so two samples that retry never see the same draws; tid 0's stream is the reference's process-global xor128 state
  * (seeded 123456789..., advanced by node_update's LUT build and by every retry), so ONE render thread reproduces the
- * reference's sequential output exactly (STRICT precision). */
+ * reference's sequential output exactly (STRICT precision).
+ * Output fields: as the reference, the call UPDATES the caller's AtCameraOutput in place -- origin, dir written; weight set to 0
+ * (zoic.cpp:1825/1952) or multiplied by the exposure factor (zoic.cpp:1981-1987); dOdy/dDdy written for retried rays only;
+ * dOdx/dDdx never touched -- whereas zoic_create_rays_arnold writes whole rows from a zero-initialised output with weight 1.
+ * For an output that Arnold hands in (zeroed, weight 1) the two agree.  THINLENS is evaluated in the reference's arithmetic in
+ * every precision mode here; under ZOIC_PRECISION_FAST with opticalVignettingDistance > 0 the batch entry points use the fast
+ * arithmetic, so the same sample can differ in low-order bits between the two (decisions never differ). */
 zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output,
                                    uint16_t tid);
 /* camera_reverse_ray, zoic.cpp:1992-1995: the reference returns false and writes nothing; so does this (returns 0). */
@@ -200,7 +214,7 @@ int zoic_camera_reverse_ray(const zoic_camera *cam, const zoic_vec3 *Po, float f
                             float *relative_time);
 
 /* Page-locked host memory for the buffers of zoic_create_rays_host: with pinned samples/rays the call runs as a
- * two-stream pipeline (copy-in of piece k+1 under trace + copy-out of piece k) at PCIe rate.  zoic_host_register pins
+ * three-stream pipeline (copy-in of piece k+2, trace of piece k+1 and copy-out of piece k at once) at PCIe rate.  zoic_host_register pins
  * memory the caller already owns (keep it registered across calls: registration costs more than one transfer). */
 zoic_status zoic_host_alloc(size_t bytes, void **out);
 void        zoic_host_free(void *p);

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ZOIC_AMD_LIB points at another build of the same library (A/B experiments, tools/); there is still no fallback
 LIB_PATH = os.environ.get("ZOIC_AMD_LIB") or os.path.join(HERE, "libzoic_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LENS_SURFACES = 32
 LUT_ENTRIES = 32
 
