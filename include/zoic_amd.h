@@ -131,6 +131,8 @@ typedef struct zoic_ray {
 
 /* struct cameraData (zoic.cpp:627-643) + its device tables */
 typedef struct zoic_camera zoic_camera;
+/* succesRays / vignettedRays / totalInternalReflection of struct Lensdata (zoic.cpp:533-534), printed by node_finish */
+typedef struct zoic_counters { uint64_t succesRays, vignettedRays, totalInternalReflection; } zoic_counters;
 
 /* ---- environment ---------------------------------------------------------------------------
  * The library reads three environment variables, all of them about WHERE node_update builds its tables (the tables are
@@ -225,8 +227,66 @@ zoic_status zoic_host_unregister(void *p);
 zoic_status zoic_generate_samples_device(zoic_camera *cam, uint64_t n, uint64_t ray_index_base, uint32_t width,
                                          uint32_t height, uint32_t spp, uint32_t seed, float *d_samples, void *stream);
 
+/* ---- one frame over several devices of ONE process ---------------------------------------------
+ * The reference is one process whose render threads all call camera_create_ray on one node (zoic.cpp:1752; lifetime
+ * :1565-1572, :1723-1749).  A zoic_frame is that node spread over n HIP devices of the calling process: one zoic_camera per
+ * device (identical tables: node_update is deterministic), the samples of a call split into contiguous ray-index slabs
+ * (zoic_frame_slab: 256-ray tiles, sizes differ by at most one tile), every device renders its slab with
+ * zoic_create_rays_device's kernels, and the finished rays are moved to the root device (devices[0]).  Retry streams are
+ * keyed by the GLOBAL ray index (ray_index_base + i), so the frame equals the one-device result bit for bit however many
+ * devices it is split over.  No collective library is involved: a slab is cut into chunks, chunk k travels to the root with
+ * hipMemcpyPeerAsync on the sending device's copy stream (xGMI is point to point: every peer pushes over its own link)
+ * while chunk k+1 is traced; chunks alternate between two compute streams so that one's drain runs under the next one's
+ * trace.  The root's own slab is ONE launch straight into the output; with one device the call IS
+ * zoic_create_rays_device.  The same device may be listed more than once (a 1-GPU box exercises every code path with
+ * devices = {0, 0}).
+ * Threading: zoic_frame_create / _update / _set_* / _destroy as the camera's node_* methods (one thread, nothing in flight);
+ * zoic_frame_render_* from one thread at a time per frame (a frame owns its streams and staging buffers; render threads that
+ * want concurrency create one frame each, or call zoic_create_rays_* on zoic_frame_camera(frame, i) directly). */
+typedef struct zoic_frame zoic_frame;
+typedef enum zoic_frame_layout {
+    ZOIC_FRAME_RECORDS = 0, /* n zoic_ray records (32 B/ray, flag word included) */
+    ZOIC_FRAME_PAYLOAD = 1  /* n rows of 7 f32: ox oy oz dx dy dz weight (28 B/ray, SURVEY 8e's gather; the flag word stays on
+                               the device that traced the ray) */
+} zoic_frame_layout;
+
+/* [begin, end) of device i's slab of an n-sample call over n_devices devices.  Pure arithmetic, callable without a device. */
+zoic_status zoic_frame_slab(uint64_t n, int n_devices, int i, uint64_t *begin, uint64_t *end);
+/* node_initialize for every device (zoic_camera_create each); devices[0] is the root.  Enables peer access root <-> peers. */
+zoic_status zoic_frame_create(const int *devices, int n_devices, zoic_frame **out);
+void        zoic_frame_destroy(zoic_frame *frame);          /* node_finish for every device; waits for queued work */
+int         zoic_frame_device_count(const zoic_frame *frame);
+zoic_camera *zoic_frame_camera(zoic_frame *frame, int i);   /* device i's camera (getters, counters, per-sample calls) */
+/* the camera's setters and node_update, applied to every device's camera (first failure is returned) */
+zoic_status zoic_frame_set_bokeh_image(zoic_frame *frame, int width, int height, int nchannels, const float *pixels);
+zoic_status zoic_frame_set_lens_text(zoic_frame *frame, const char *text, size_t len);
+zoic_status zoic_frame_set_precision(zoic_frame *frame, zoic_precision mode);
+zoic_status zoic_frame_set_seed(zoic_frame *frame, uint32_t seed);
+zoic_status zoic_frame_update(zoic_frame *frame, const zoic_params *p);
+/* rays per chunk of a peer's slab (rounded down to 256-ray tiles); 0 = default: a quarter of a slab, at least 64 MB of payload */
+zoic_status zoic_frame_set_chunk_rays(zoic_frame *frame, uint64_t rays);
+/* camera_create_ray over n samples resident on the devices.
+ *   d_samples : n_devices pointers; d_samples[i] = device i's slab, (end - begin) x (sx, sy, lensx, lensy) f32 in device i's
+ *               memory, complete before the call.  NULL: the slabs zoic_frame_generate_samples produced for this (n, base).
+ *   d_out     : root-device memory for n records / payload rows (16-byte aligned), in global ray order
+ *   root_stream : a stream of the root device (NULL = its default stream).  The call is asynchronous; everything it queued is
+ *               ordered before whatever is queued on root_stream afterwards, and behind what was queued on it before. */
+zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base,
+                                     void *d_out, zoic_frame_layout layout, void *root_stream);
+/* same without moving anything to the root: every device leaves its slab's records in its own memory (d_rays[i], or the
+ * frame's own buffers when d_rays is NULL) -- the "compute only" leg of a scaling measurement */
+zoic_status zoic_frame_render_local(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base,
+                                    zoic_ray *const *d_rays);
+/* host buffers: device i moves its slab in and out over ITS OWN PCIe link (zoic_create_rays_host per device, all at once);
+ * nothing crosses xGMI.  Returns when h_rays is complete. */
+zoic_status zoic_frame_render_host(zoic_frame *frame, uint64_t n, const float *h_samples, uint64_t ray_index_base, zoic_ray *h_rays);
+/* synthetic samples of zoic_generate_samples_device, every device its own slab, into frame-owned buffers */
+zoic_status zoic_frame_generate_samples(zoic_frame *frame, uint64_t n, uint64_t ray_index_base, uint32_t width, uint32_t height,
+                                        uint32_t spp, uint32_t seed);
+zoic_status zoic_frame_synchronize(zoic_frame *frame);      /* every stream of the frame, on every device */
+zoic_status zoic_frame_get_counters(zoic_frame *frame, zoic_counters *sum);   /* summed over the devices */
+
 /* ---- statistics (node_finish prints them, zoic.cpp:1729-1732) ------------------------------ */
-typedef struct zoic_counters { uint64_t succesRays, vignettedRays, totalInternalReflection; } zoic_counters;
 zoic_status zoic_camera_get_counters(zoic_camera *cam, zoic_counters *out); /* synchronises the device */
 zoic_status zoic_camera_reset_counters(zoic_camera *cam);
 
@@ -243,6 +303,8 @@ typedef struct zoic_lens_info {
     float lutMaxX[ZOIC_LUT_ENTRIES], lutMaxY[ZOIC_LUT_ENTRIES], lutMinX[ZOIC_LUT_ENTRIES], lutMinY[ZOIC_LUT_ENTRIES];
     int32_t bokehWidth, bokehHeight;
     int32_t fastRunsStrict; /* 1: this camera is outside the FAST modes' domain (see zoic_precision) and runs STRICT whatever the mode */
+    uint32_t precomputeTIR; /* totalInternalReflection bumps of node_update's own traces (zoic.cpp:1135 ff.) that the camera's
+                               counters currently include (0 after zoic_camera_reset_counters) */
 } zoic_lens_info;
 zoic_status zoic_camera_get_info(const zoic_camera *cam, zoic_lens_info *out);
 /* copies of the bokeh CDF tables (bokehProbability, zoic.cpp:222-417); arrays sized by bokehWidth/Height */

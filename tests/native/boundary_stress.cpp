@@ -3,6 +3,8 @@
 // Exercises the host C++ of the product (capi.cpp, lens_system.cpp) through the C-ABI only, the way a renderer would:
 //   part 1 (always, no GPU needed): several threads each own a tables-only camera (ZOIC_DEVICE_NONE) and run node_update's
 //           whole host precompute -- parse, focus, exit-pupil LUT, bokeh CDF -- plus the error paths;
+//   part 3 (when a HIP device is visible): zoic_frame_* over devices {0, 0, 0} -- update threads, host-render threads, chunked
+//          device render -- against one camera's result
 //   part 2 (when a HIP device is visible): 16 render threads hammer ONE camera with camera_create_ray / Arnold-layout /
 //           host-buffer calls, the contract of zoic.cpp:1752; the results are checked against a serial replay.
 // Exit code 0 = clean; the sanitizer runtime turns any report into a non-zero exit.
@@ -165,6 +167,44 @@ int main(int argc, char **argv)
         }
     } else {
         std::printf("part 2 skipped: no HIP device\n");
+    }
+    // part 3: one camera node over three "devices" of this process (zoic_frame_*, csrc/frame.cpp): the frame's own update
+    // threads, its per-device host-render threads and the event-chained device render, compared with one camera's result
+    if (zoic_device_count() > 0 && renderThreads > 0) {
+        const int devices[3] = {0, 0, 0};
+        zoic_frame *frame = nullptr;
+        CHECK(zoic_frame_create(devices, 3, &frame) == ZOIC_OK);
+        zoic_camera *cam = render_camera();
+        CHECK(cam != nullptr);
+        if (frame && cam) {
+            zoic_params p;
+            zoic_params_default(&p);
+            p.lensDataPath = "mem:triplet"; p.focalLength = 5.0f; p.fStop = 2.5f;
+            CHECK(zoic_frame_set_lens_text(frame, kTriplet, std::strlen(kTriplet)) == ZOIC_OK);
+            CHECK(zoic_frame_update(frame, &p) == ZOIC_OK);
+            CHECK(zoic_frame_set_chunk_rays(frame, 4096) == ZOIC_OK);
+            const size_t m = 100003;
+            unsigned s = 99u;
+            auto rnd = [&s]() { s = s * 1664525u + 1013904223u; return static_cast<float>(s >> 8) * (1.0f / 16777216.0f); };
+            std::vector<float> smp(m * 4);
+            for (size_t k = 0; k < m; ++k) { smp[4 * k] = 2.0f * rnd() - 1.0f; smp[4 * k + 1] = (2.0f * rnd() - 1.0f) * 0.5625f; smp[4 * k + 2] = rnd(); smp[4 * k + 3] = rnd(); }
+            std::vector<zoic_ray> one(m), many(m);
+            CHECK(zoic_create_rays_host(cam, m, smp.data(), nullptr, 424242, one.data()) == ZOIC_OK);
+            for (int rep = 0; rep < 3; ++rep) {
+                std::memset(many.data(), 0, m * sizeof(zoic_ray));
+                CHECK(zoic_frame_render_host(frame, m, smp.data(), 424242, many.data()) == ZOIC_OK);
+                CHECK(std::memcmp(one.data(), many.data(), m * sizeof(zoic_ray)) == 0);
+            }
+            CHECK(zoic_frame_generate_samples(frame, m, 0, 640, 360, 4, 1) == ZOIC_OK);
+            CHECK(zoic_frame_render_local(frame, m, nullptr, 0, nullptr) == ZOIC_OK);
+            CHECK(zoic_frame_synchronize(frame) == ZOIC_OK);
+            zoic_counters fc{};
+            CHECK(zoic_frame_get_counters(frame, &fc) == ZOIC_OK);
+            CHECK(fc.succesRays + fc.vignettedRays == 4 * m);
+        }
+        zoic_camera_destroy(cam);
+        zoic_frame_destroy(frame);
+        std::printf("part 3: one frame over 3 lanes of device 0, failures %d\n", g_failures.load());
     }
     // Leave without running the ROCm runtime's exit-time destructors: under ROCm's AddressSanitizer runtime they trip an
     // internal CHECK of its device allocator (sanitizer_allocator_device.h, "dev_runtime_unloaded_") inside

@@ -36,3 +36,4 @@ def test_sixteen_render_threads_are_clean_under_sanitizers(gpu, kind):
     r = _run(exe, [2, 16, 250], kind)
     assert r.returncode == 0, r.stdout[-8000:]
     assert "part 2: 16 render threads x 250 calls on one camera, failures 0" in r.stdout
+    assert "part 3: one frame over 3 lanes of device 0, failures 0" in r.stdout

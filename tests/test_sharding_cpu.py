@@ -26,6 +26,24 @@ def test_slabs_partition_the_frame():
         slab_for_rank(10, 2, 2)
 
 
+def test_the_library_partitions_like_the_python_mirror():
+    """zoic_frame_slab (the C-ABI's partition of a frame over the devices of one process, csrc/frame.cpp) is the same
+    function as sharding.slab_for_rank (one process per GPU): a frame is cut the same way whichever host drives it.
+    Pure host arithmetic -- no device needed."""
+    import random
+    from zoic_amd import ZoicError, frame_slab
+    from zoic_amd.sharding import slab_for_rank
+    rnd = random.Random(4)
+    for _ in range(5000):
+        n = rnd.choice([0, 1, 255, 256, 257, 132710400, 2123366400, rnd.randrange(1, 1 << 40)])
+        world = rnd.randrange(1, 65)
+        r = rnd.randrange(world)
+        assert frame_slab(n, world, r) == slab_for_rank(n, r, world)
+    for bad in ((10, 0, 0), (10, 2, 2), (10, 2, -1)):
+        with pytest.raises(ZoicError):
+            frame_slab(*bad)
+
+
 def _worker(rank, world, port, n, outdir):
     sys.path.insert(0, ROOT)
     import torch

@@ -15,6 +15,7 @@ LUT_ENTRIES = 32
 
 THINLENS, RAYTRACED, LENS_NONE = 0, 1, 2
 PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_UNCHECKED = 0, 1, 2
+FRAME_RECORDS, FRAME_PAYLOAD = 0, 1
 
 STATUS_NAMES = ["ZOIC_OK", "ZOIC_ERR_INVALID_ARGUMENT", "ZOIC_ERR_LENS_PATH", "ZOIC_ERR_LENS_COLUMNS",
                 "ZOIC_ERR_LENS_PARSE", "ZOIC_ERR_MULTI_APERTURE", "ZOIC_ERR_NO_APERTURE", "ZOIC_ERR_TOO_MANY_LENSES",
@@ -62,7 +63,7 @@ class LensInfo(C.Structure):
                 + [(n, C.c_float * MAX_LENS_SURFACES) for n in ("curvature", "thickness", "ior", "aperture", "center")]
                 + [("lutSize", C.c_int32), ("lutKey", C.c_float * LUT_ENTRIES)]
                 + [(n, C.c_float * LUT_ENTRIES) for n in ("lutMaxX", "lutMaxY", "lutMinX", "lutMinY")]
-                + [("bokehWidth", C.c_int32), ("bokehHeight", C.c_int32), ("fastRunsStrict", C.c_int32)])
+                + [("bokehWidth", C.c_int32), ("bokehHeight", C.c_int32), ("fastRunsStrict", C.c_int32), ("precomputeTIR", C.c_uint32)])
 
 
 # every symbol include/zoic_amd.h declares: name -> (restype, argtypes)
@@ -91,6 +92,23 @@ SYMBOLS = {
     "zoic_host_register": (C.c_int, [_vp, C.c_size_t]),
     "zoic_host_unregister": (C.c_int, [_vp]),
     "zoic_generate_samples_device": (C.c_int, [_vp, _u64, _u64, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "zoic_frame_slab": (C.c_int, [_u64, C.c_int, C.c_int, C.POINTER(_u64), C.POINTER(_u64)]),
+    "zoic_frame_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "zoic_frame_destroy": (None, [_vp]),
+    "zoic_frame_device_count": (C.c_int, [_vp]),
+    "zoic_frame_camera": (_vp, [_vp, C.c_int]),
+    "zoic_frame_set_bokeh_image": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "zoic_frame_set_lens_text": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "zoic_frame_set_precision": (C.c_int, [_vp, C.c_int]),
+    "zoic_frame_set_seed": (C.c_int, [_vp, _u32]),
+    "zoic_frame_update": (C.c_int, [_vp, C.POINTER(Params)]),
+    "zoic_frame_set_chunk_rays": (C.c_int, [_vp, _u64]),
+    "zoic_frame_render_device": (C.c_int, [_vp, _u64, C.POINTER(_vp), _u64, _vp, C.c_int, _vp]),
+    "zoic_frame_render_local": (C.c_int, [_vp, _u64, C.POINTER(_vp), _u64, C.POINTER(_vp)]),
+    "zoic_frame_render_host": (C.c_int, [_vp, _u64, _vp, _u64, _vp]),
+    "zoic_frame_generate_samples": (C.c_int, [_vp, _u64, _u64, _u32, _u32, _u32, _u32]),
+    "zoic_frame_synchronize": (C.c_int, [_vp]),
+    "zoic_frame_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "zoic_camera_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "zoic_camera_reset_counters": (C.c_int, [_vp]),
     "zoic_camera_get_info": (C.c_int, [_vp, C.POINTER(LensInfo)]),

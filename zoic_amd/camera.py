@@ -285,7 +285,7 @@ class ZoicCamera:
                     lutKeys=f(i.lutKey, i.lutSize),
                     lutBoxes=np.stack([f(i.lutMaxX, i.lutSize), f(i.lutMaxY, i.lutSize), f(i.lutMinX, i.lutSize),
                                        f(i.lutMinY, i.lutSize)], 1),
-                    bokehWidth=i.bokehWidth, bokehHeight=i.bokehHeight, fastRunsStrict=bool(i.fastRunsStrict))
+                    bokehWidth=i.bokehWidth, bokehHeight=i.bokehHeight, fastRunsStrict=bool(i.fastRunsStrict), precomputeTIR=int(i.precomputeTIR))
 
     def bokeh_tables(self):
         i = self.info()

@@ -31,6 +31,7 @@
 #include "kernels.hpp"
 #include "mailbox.hpp"
 #include "lens_system.hpp"
+#include "host_util.hpp"
 
 #pragma STDC FP_CONTRACT OFF
 
@@ -49,6 +50,11 @@ zoic_status fail(zoic_status s, const std::string &msg)
     g_lastError = msg;
     return s;
 }
+}  // namespace
+namespace zoic {
+zoic_status fail_status(zoic_status s, const std::string &msg) { return fail(s, msg); }   // frame.cpp reports through the same thread-local text
+}
+namespace {
 
 #define ZOIC_HIP(expr)                                                                                       \
     do {                                                                                                     \
@@ -61,22 +67,6 @@ struct OwnedParams {  // struct cameraParams, zoic.cpp:544-612
     zoic_params p{};
     std::string bokehPath, lensDataPath;
     bool valid = false;
-};
-
-template <class T>
-struct DeviceBuffer {
-    T *ptr = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t n)
-    {
-        if (n <= cap) return hipSuccess;
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr; cap = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
-        if (e == hipSuccess) cap = n;
-        return e;
-    }
-    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
 // page-locked host memory, mapped into the device's address space (zero-copy for the per-sample adapter, async D2H target
@@ -96,23 +86,6 @@ struct PinnedBuffer {
         return hipSuccess;
     }
     void release() { if (host) (void)hipHostFree(host); host = dev = nullptr; cap = 0; }
-};
-
-// every entry point runs on the camera's device and leaves the calling thread's current device as it found it
-class DeviceGuard {
-    int prev_ = -1;
-    bool switched_ = false;
-    hipError_t err_ = hipSuccess;
-public:
-    explicit DeviceGuard(int device)
-    {
-        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
-        if (prev_ != device) { err_ = hipSetDevice(device); switched_ = err_ == hipSuccess && prev_ >= 0; }
-    }
-    ~DeviceGuard() { if (switched_) (void)hipSetDevice(prev_); }
-    hipError_t error() const { return err_; }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
 // One launch's work cursors.  `done` is recorded behind the launch that used the slot last; the next launch to draw the
@@ -253,6 +226,7 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
         return precision == ZOIC_PRECISION_FAST ? 1 : 2;
     }
     uint32_t seed = 1;
+    uint32_t tirInCounters = 0;    // the precompute's TIR bumps the counters currently include (zoic_lens_info::precomputeTIR)
     bool updated = false;
     bool lutOnHost = false, lutHostDraws = false;
     // pending inputs; the dirty flags force the rebuild on the next update even under an unchanged path
@@ -966,6 +940,7 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
             if (!g_lastError.empty()) return ZOIC_ERR_HIP;
             // counters restart with the lens (zoic.cpp:1626-1628); the precompute's TIR bumps stay in (zoic.cpp:1135 ff.)
             DeviceCounters zero{0, 0, cam->lens.precomputeTIR, {}};
+            cam->tirInCounters = cam->lens.precomputeTIR;
             if (onDevice) {
                 ZOIC_HIP(hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters)));
                 ZOIC_HIP(hipMemcpy(cam->dCounters, &zero, sizeof(zero), hipMemcpyHostToDevice));   // set 0 carries the precompute's bumps
@@ -1313,6 +1288,7 @@ zoic_status zoic_camera_reset_counters(zoic_camera *cam)
     ZOIC_HIP(cam->mail.stop());
     ZOIC_HIP(hipDeviceSynchronize());
     ZOIC_HIP(hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters)));
+    cam->tirInCounters = 0;
     return ZOIC_OK;
 }
 
@@ -1338,6 +1314,7 @@ zoic_status zoic_camera_get_info(const zoic_camera *cam, zoic_lens_info *out)
         out->lutMinX[i] = L.lutBox[i].minX; out->lutMinY[i] = L.lutBox[i].minY;
     }
     out->bokehWidth = cam->image.x; out->bokehHeight = cam->image.y;
+    out->precomputeTIR = cam->device == ZOIC_DEVICE_NONE ? L.precomputeTIR : cam->tirInCounters;
     out->fastRunsStrict = (cam->params.valid && cam->params.p.lensModel == ZOIC_RAYTRACED && !cam->fastDomain) ? 1 : 0;
     return ZOIC_OK;
 }

@@ -164,6 +164,17 @@ __global__ __launch_bounds__(kBlock) void expand_outputs_kernel(const RayRecord 
     }
 }
 
+// 32-byte records -> rows of 7 floats (origin, dir, weight): the 28-byte payload SURVEY 8(e) gathers on the root GPU.  One lane
+// per output float: the stores are fully coalesced, the loads hit each record's sector once per wave.
+__global__ __launch_bounds__(kBlock) void pack_payload_kernel(const RayRecord *__restrict__ rays, float *__restrict__ out7, uint64_t n)
+{
+    const uint64_t total = n * 7u, stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t ray = t / 7u;
+        out7[t] = reinterpret_cast<const float *>(rays + ray)[static_cast<uint32_t>(t - ray * 7u)];
+    }
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline unsigned grid_for(uint64_t n)
 {
@@ -212,6 +223,13 @@ int launch_pack_inputs(const float *d_inputs7, float *d_samples4, uint64_t n, vo
     if (n == 0) return 0;
     hipLaunchKernelGGL(pack_inputs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_inputs7,
                        reinterpret_cast<float4 *>(d_samples4), n);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_pack_payload(const RayRecord *d_rays, float *d_out7, uint64_t n, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_payload_kernel, dim3(grid_for(n * 7u)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_rays, d_out7, n);
     return static_cast<int>(hipGetLastError());
 }
 

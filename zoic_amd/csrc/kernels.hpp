@@ -84,5 +84,7 @@ int launch_lut_probes(const KolbTable &table, float originX, const float *d_lens
 // Arnold AoS <-> planes (AtCameraInput 28 B -> sample 16 B; planes -> AtCameraOutput 84 B)
 int launch_pack_inputs(const float *d_inputs7, float *d_samples4, uint64_t n, void *stream);
 int launch_expand_outputs(const RayRecord *d_rays, float *d_out21, uint64_t n, void *stream);
+// records -> 28-byte payload rows (ox oy oz dx dy dz weight): what a multi-device frame moves to its root (frame.cpp)
+int launch_pack_payload(const RayRecord *d_rays, float *d_out7, uint64_t n, void *stream);
 
 }  // namespace zoic
