@@ -7,11 +7,15 @@ One "step" = one pass of camera_create_ray over one full frame of synthetic samp
 F_2.0_DOUBLE_GAUSS + image-based bokeh sampler, 3840x2160x16spp = 132,710,400 samples), samples already resident
 in HBM, rays written to HBM.  Rank 0 prints ONE JSON line (kept under 6 KB: what a field means is said once, in `notes`):
 
-  value / ms_per_step   the headline workload, K timed steps between barriers.  N>1 (torch.distributed.run, one rank per
-                        GPU): every rank renders its own frame of the headline size -- the path shards by independent
-                        samples with no data-path collective, so this is weak scaling;
-  roofline              the launch against the HBM roofline (per the bench contract), kernel time by HIP events on the launch
-                        stream, + the VALU-issue figures of the bound that actually binds the Kolb kernels;
+  value / ms_per_step   N=1: the headline frame, K timed steps between barriers.  N>1 (one rank per GPU; `python bench.py --gpus N`
+                        without a launcher re-executes itself under torch.distributed.run): north_star's number -- the SAME
+                        frame rendered ONCE per step in N ray-index slabs INCLUDING the RCCL gather of the 28-byte payload on
+                        rank 0 (strong scaling); compute_only, the weak-scaling figure (every rank its own frame, no
+                        collective), the root's ingest rate against its (N-1) x 153 GB/s of xGMI and the single-process
+                        zoic_frame_* path (rank 0 alone driving all N devices through the C-ABI) are printed beside it;
+  roofline              bound = "valu" for the Kolb configs ("hbm" for the thin lens); achieved / peak / frac = the launch against
+                        the HBM roofline at SURVEY 8(d)'s 44 B/ray (kernel time by HIP events on the launch stream), flop_frac =
+                        oracle-counted FLOP/ray x rays/s against 157 TFLOP/s, valu_frac = VALU issue;
   parity                direction RMSE / decision flips of the benchmarked mode against the oracle;
   configs               the other BASELINE.json configs at their true sizes (C1, C2, C4, C5 fast + C3 strict);
   sharded_frame         BASELINE.json configs 4/5 as north_star states them: ONE C4 / C5 frame in ray-index slabs over the N
@@ -30,18 +34,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_RAY = 48  # 16 B sample in + one 32 B ray record out (28 B origin/dir/weight of SURVEY 8(d) + the 4 B flag word)
-SURVEY_BYTES_PER_RAY = 44  # SURVEY 8(d)'s figure (16 + 28): reported next to it
+RECORD_BYTES_PER_RAY = 48  # what the kernels move: 16 B sample in + one 32 B ray record out (SURVEY's 28 B + the 4 B flag word): frac48
+ALGO_BYTES_PER_RAY = 44    # SURVEY 8(d)'s algorithmic figure (16 B in + 28 B origin/dir/weight out): roofline.achieved / frac
+FP32_PEAK_TFLOPS = 157.0   # MI355X FP32 vector peak, FMA counted as 2
+XGMI_LINK_GBS = 153.0      # one xGMI link, one direction (MI355X_MICROARCH.md): the root of a gather ingests on N-1 of them
+NORTH_STAR_MRAYS_1GPU = 1000.0   # north_star: >= 1 Grays/s on one MI355X, >= 6x that at 8 GPUs
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 VALU_PEAK_ARCH_TWIPS = 1.2288   # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md "Wave scheduling")
 CPU_SLAB_RAYS = 16_588_800       # the fixed slab (= config 2's full size) the CPU legs are quoted on
 
 NOTES = {
-    "roofline": "achieved = 48 B/ray (16 B sample + 32 B record) x rays / kernel_ms; kernel_ms = the launch (main kernel + STRICT kernel over "
-                "its work list) by HIP events on the launch stream; frac44 = the same at SURVEY 8(d)'s 44 B/ray; traffic, lane_instr, "
-                "lane_util = committed rocprofv3 PMC run of this (config, mode), profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE), "
-                "not measured in this process; valu_frac = wave64 VALU instr/s over 1024 SIMDs x 2.4 GHz / 2; the Kolb kernels are "
-                "bound by VALU issue, the thin lens (C1) by HBM",
+    "roofline": "achieved = 44 B/ray (SURVEY 8d: 16 B sample + 28 B origin/dir/weight) x rays / kernel_ms; kernel_ms = the launch (main kernel + "
+                "STRICT kernel over its work list) by HIP events on the launch stream; frac48 = the same with the 32 B record the kernels "
+                "really write; flop_frac = FLOP/ray counted by the oracle (profiles/flop_model_r04.json: 106 x interface visits + 130 x "
+                "tries) x rays/s over 157 TFLOP/s; traffic, lane_instr, lane_util = the committed rocprofv3 PMC run of this (config, "
+                "mode), profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE) -- null when the kernel sources have changed since "
+                "(csrc_sha16); valu_frac = wave64 VALU instr/s over 1024 SIMDs x 2.4 GHz / 2; the Kolb kernels are bound by VALU issue "
+                "(bound: valu), the thin lens (C1) by HBM",
+    "multi_gpu": "value = ONE headline frame per step in N ray-index slabs incl. the gather of the 28 B/ray payload on rank 0 (RCCL "
+                 "batch_isend_irecv, chunks overlapped with the trace); root_ingest_frac = bytes into rank 0 per second over (N-1) x 153 "
+                 "GB/s: a gather to ONE root is bounded by its links, 3.25 GB of a C3 frame >= 3.0 ms at 8 GPUs against 3.3 ms to render "
+                 "the whole frame on one GPU, so speed-up over one GPU cannot exceed ~1x with the gather in -- the north-star target is "
+                 "absolute (>= 6x 1 Grays/s at 8 GPUs = target_mrays_s); weak = every rank its own frame, no collective; "
+                 "single_process_frame = rank 0 alone driving all N devices through zoic_frame_* (hipMemcpyPeerAsync gather)",
     "mode": "fast = ZOIC_PRECISION_FAST: f32 without the reference's scattered f64 intermediates, decisions at ill-conditioned "
             "interfaces re-taken in STRICT (flips = rays whose try count / weight differs from the oracle's); strict = bit-exact",
     "parity": "256 Ki samples from the middle of the frame against the oracle (CPU restatement of zoic.cpp); rmse over rays with "
@@ -57,7 +72,8 @@ NOTES = {
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE if a launcher set it, else 1)")
+    ap.add_argument("--dry-launch", action="store_true", help="CPU self-test of the launcher: ranks meet over gloo, rank 0 prints the world it saw")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
@@ -71,7 +87,8 @@ def parse_args():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of one repetition of a CPU baseline leg")
-    ap.add_argument("--sharded-timeout", type=int, default=240, help="N > 1: seconds the ShardedFrame section may take before the line is printed without it")
+    ap.add_argument("--no-single-process", action="store_true", help="N > 1: skip the zoic_frame_* measurement (rank 0 driving all devices)")
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="N > 1: seconds everything behind the weak-scaling leg (gathers included) may take before the line is printed with what has been measured")
     ap.add_argument("--gather-chunk-mb", type=int, default=0, help="payload MB per gather chunk (0: a quarter of a slab, at least 64 MB)")
     return ap.parse_args()
 
@@ -197,26 +214,58 @@ def parity_probe(cam, cfg_name, precision):
 
 
 # ------------------------------------------------------------------------------------------------- GPU legs
+def csrc_sha16():
+    """Fingerprint of the kernel sources (every .hip / .hpp of zoic_amd/csrc): a PMC entry of profiles/pmc_traffic.json is only
+    replayed when it was taken on these sources (tools/collect_profiles.py stamps it)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zoic_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_entry(cfg_name, precision):
-    """HBM bytes and VALU instruction counts of the last committed rocprofv3 PMC run of this (config, mode)."""
+    """HBM bytes and VALU instruction counts of the committed rocprofv3 PMC run of this (config, mode) -- None (=> traffic null)
+    when the entry is missing or was taken on other kernel sources than the ones this tree holds."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s_%s" % (cfg_name, precision)) or None
+        ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s_%s" % (cfg_name, precision)) or None
     except Exception:
         return None
+    if ent is None or ent.get("csrc_sha16") != csrc_sha16():
+        return None
+    return ent
+
+
+def flop_per_ray(cfg_name):
+    """Algorithmic FLOP per ray: re-measured with the oracle's counters (tools/flop_model.py -> profiles/flop_model_r04.json),
+    SURVEY 8(d)'s probe figures when that file is missing."""
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "flop_model_r04.json")))[cfg_name]["flop_per_ray"])
+    except Exception:
+        return {"C2": 1500.0, "C3": 1700.0, "C4": 1550.0, "C5": 3900.0}.get(cfg_name)
 
 
 def roofline_block(cfg_name, precision, n, kernel_ms, thin):
     achieved = ALGO_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9
     ent = pmc_entry(cfg_name, precision)
-    roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(ent["hbm_bytes_per_launch"]) if ent else None, "kernel_ms": round(kernel_ms, 4),
-            "frac44": round(SURVEY_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+    roof = {"bound": "hbm" if thin else "valu", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": round(ent["hbm_bytes_per_launch"]) if ent else None, "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": ALGO_BYTES_PER_RAY,
+            "frac48": round(RECORD_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "kernel": "thin_rays_kernel" if thin else {"fast": "kolb_pool_guard_kernel + kolb_pool_strict_listed_kernel", "unchecked": "kolb_pool_fast_kernel",
                                                         "strict": "kolb_pool_strict_kernel"}[precision]}
+    fl = None if thin else flop_per_ray(cfg_name)
+    if fl:
+        tf = fl * n / (kernel_ms * 1e-3) / 1e12
+        roof.update(flop_per_ray=round(fl), tflops=round(tf, 1), flop_frac=round(tf / FP32_PEAK_TFLOPS, 3))
     if ent and ent.get("lane_instr_per_ray") and not thin:
         rate = ent["lane_instr_per_ray"] / 64.0 * n / (kernel_ms * 1e-3) / 1e12
         roof.update(lane_instr=round(ent["lane_instr_per_ray"]), lane_util=round(ent.get("valu_thread_util", 0.0), 3),
                     valu_frac=round(rate / VALU_PEAK_ARCH_TWIPS, 3))
+    if ent is None:
+        roof["pmc"] = "no committed PMC run of these kernel sources (csrc_sha16 %s)" % csrc_sha16()
     return roof
 
 
@@ -277,13 +326,15 @@ def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, par
     return ent
 
 
-def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, steps, chunk_mb):
-    """north_star configs 4/5: ONE frame in ray-index slabs over the ranks; compute-only and gather-inclusive rates."""
+def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, steps, chunk_mb, precision="fast", warmup=1, ent=None):
+    """ONE frame of `cfg_name` in ray-index slabs over the ranks (north_star): compute-only and gather-inclusive
+    rates, K timed steps each between barriers, max over ranks.  `ent` is filled as results arrive (a watchdog may print it)."""
     from zoic_amd.sharding import PAYLOAD_FLOATS, ShardedFrame
     from zoic_amd.workloads import CONFIGS, ray_count
     cfg = CONFIGS[cfg_name]
     n_total = ray_count(cfg_name)
-    cam = make_camera(cfg_name, "fast", local_rank)
+    ent = {} if ent is None else ent
+    cam = make_camera(cfg_name, precision, local_rank)
     chunk_bytes = (chunk_mb << 20) if chunk_mb else None
     frame = ShardedFrame(n_total, dist if world > 1 else None, dev, None, dst=0, chunk_bytes=chunk_bytes)
     lo, hi = frame.slabs[rank]
@@ -301,8 +352,9 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
     frame.generate = generate
 
     def timed(gather):
-        turn[0] = 0
-        frame.run(gather=gather)
+        for _ in range(max(1, warmup)):
+            turn[0] = 0
+            frame.run(gather=gather)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier(device_ids=[local_rank])
@@ -321,15 +373,16 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
+    ent.update(config=cfg_name, mode=precision, rays=n_total, n_gpus=world, steps=steps, scaling="strong", sub_launches_per_slab=len(frame.chunks[rank]))
     t_compute = timed(False)
-    t_gather = timed(True) if world > 1 else None
-    ent = {"config": cfg_name, "rays": n_total, "n_gpus": world, "steps": steps, "scaling": "strong", "sub_launches_per_slab": len(frame.chunks[rank]),
-           "compute_only": round(n_total * steps / t_compute / 1e6, 1), "compute_ms": round(t_compute / steps * 1e3, 3)}
-    if t_gather is not None:
+    ent.update(compute_only=round(n_total * steps / t_compute / 1e6, 1), compute_ms=round(t_compute / steps * 1e3, 3))
+    if world > 1:
+        t_gather = timed(True)
         payload = 4 * PAYLOAD_FLOATS
         into_root = payload * (n_total - (frame.slabs[0][1] - frame.slabs[0][0]))
+        ingest = into_root * steps / t_gather / 1e9
         ent.update(with_gather=round(n_total * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3), chunk_mb=frame.chunk_bytes >> 20,
-                   root_ingest_gb_s=round(into_root * steps / t_gather / 1e9, 1))
+                   root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((world - 1) * XGMI_LINK_GBS), 3))
         # rank 0 holds the gathered frame: a peer's chunk must equal what this GPU computes for the same global rays
         full = frame.run(gather=True)
         torch.cuda.synchronize()
@@ -340,6 +393,62 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
             ent["bit_identical_to_single_gpu"] = bool(torch.equal(mine.contiguous().view(torch.int32), full[a:b].view(torch.int32)))
     cam.close()
     del samples, recs, frame
+    torch.cuda.empty_cache()
+    return ent
+
+
+def single_process_frame_entry(torch, cfg_name, precision, devices, steps, warmup, ent=None):
+    """The same frame through the C-ABI's zoic_frame_* (csrc/frame.cpp): THIS process alone drives every device -- the form a
+    C++ plug-in can call (the reference is one process).  Gather = hipMemcpyPeerAsync of the 28-byte payload to devices[0]."""
+    from zoic_amd import FRAME_PAYLOAD, PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, ZoicFrame
+    from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_count
+    cfg = CONFIGS[cfg_name]
+    n = ray_count(cfg_name)
+    ent = {} if ent is None else ent
+    ent.update(config=cfg_name, devices=len(devices))
+    frame = ZoicFrame(devices)
+    if cfg["bokeh"]:
+        frame.set_bokeh_image(hexagon_bokeh())
+    frame.update(**camera_params(cfg_name))
+    frame.set_precision({"fast": PRECISION_FAST, "unchecked": PRECISION_FAST_UNCHECKED, "strict": PRECISION_STRICT}[precision])
+    frame.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1)
+    root = torch.device("cuda", devices[0])
+    out = torch.empty((n, 7), dtype=torch.float32, device=root)
+
+    def timed(call):
+        for _ in range(max(1, warmup)):
+            call()
+        frame.synchronize()
+        torch.cuda.synchronize(root)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call()
+        torch.cuda.synchronize(root)     # a render is ordered on the root's current stream ...
+        frame.synchronize()              # ... and render_local on the frame's own
+        return time.perf_counter() - t0
+    with torch.cuda.device(root):
+        t_local = timed(lambda: frame.render_local(n))
+        ent.update(compute_only=round(n * steps / t_local / 1e6, 1), compute_ms=round(t_local / steps * 1e3, 3))
+        t_gather = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD))
+        into_root = 28 * (n - (frame.slab(n, 0)[1] - frame.slab(n, 0)[0]))
+        ent.update(with_gather=round(n * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3))
+        if len(devices) > 1:
+            ingest = into_root * steps / t_gather / 1e9
+            ent.update(root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((len(devices) - 1) * XGMI_LINK_GBS), 3))
+        # the whole frame against ONE camera on the root device
+        cam = make_camera(cfg_name, precision, devices[0])
+        s = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1)
+        ref = cam.create_rays(s)["rays"]
+        torch.cuda.synchronize(root)
+        same = True
+        step = 1 << 24
+        for a in range(0, n, step):     # in pieces: no second whole-frame temporary
+            same = same and bool(torch.equal(ref[a:a + step, :7].contiguous().view(torch.int32), out[a:a + step].view(torch.int32)))
+        ent["bit_identical_to_single_gpu"] = same
+        cam.close()
+        del ref, s
+    frame.close()
+    del out
     torch.cuda.empty_cache()
     return ent
 
@@ -397,6 +506,58 @@ def host_path_entry(cam, cfg):
     return res
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def resolve_launch(args, env, device_count, argv):
+    """How many ranks this invocation means, and whether it has to start them itself.
+
+    Returns ("run", world) -- this process is one rank of `world` (a launcher exported WORLD_SIZE, or N = 1) -- or
+    ("exec", command) -- `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU.
+    Raises SystemExit (non-zero) when --gpus contradicts the launcher's WORLD_SIZE or asks for more GPUs than the node has."""
+    env_world = int(env["WORLD_SIZE"]) if env.get("WORLD_SIZE") else None
+    want = args.gpus if args.gpus is not None else (env_world or 1)
+    if want < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is not None:
+        if want != env_world:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (want, env_world))
+        if not args.dry_launch and device_count < env_world:
+            raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible: one rank per GPU" % (env_world, device_count))
+        return "run", env_world
+    if want == 1:
+        return "run", 1
+    if not args.dry_launch and device_count < want:
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible on this node (one rank per GPU; nothing was measured)" % (want, device_count))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(want), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return "exec", cmd
+
+
+def dry_launch(world):
+    """CPU self-test of the launcher (tests/test_sharding_cpu.py): the ranks torch.distributed.run started meet over gloo."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"dry_launch": True, "world": dist.get_world_size(), "expected": world, "sum": int(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def flush_c_stdio():
+    import ctypes
+    ctypes.CDLL(None).fflush(None)   # RCCL prints its banner through C stdio (block-buffered on a pipe): out with it before the line
+    sys.stdout.flush()
+
+
 def main():
     args = parse_args()
     if args.only_headline:
@@ -404,7 +565,14 @@ def main():
     import torch
     from zoic_amd.workloads import CONFIGS, ray_count
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    what, plan = resolve_launch(args, os.environ, ndev, sys.argv[1:])
+    if what == "exec":
+        flush_c_stdio()
+        os.execv(plan[0], plan)
+    world = plan
+    if args.dry_launch:
+        return dry_launch(world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -420,10 +588,11 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
 
     cfg = CONFIGS[args.config]
     frame = args.rays or ray_count(args.config)
-    n, base, n_total = frame, rank * frame, frame * world        # rank r renders frame r (distinct global ray indices)
+    n, base, n_total = frame, rank * frame, frame * world        # weak leg: rank r renders frame r (distinct global ray indices)
     cam = make_camera(args.config, args.precision, local_rank)
     elapsed, kernel_ms = time_frame(torch, cam, cfg, n, base, args.steps, args.warmup, dev, dist, local_rank)
 
@@ -437,17 +606,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.config, cfg["desc"]), "rays_per_gpu_per_step": n, "precision_mode": args.precision,
-                       "parallelism": "independent frames per GPU (dp%d), no data-path collective" % world},
+                       "parallelism": "one frame on one GPU" if world == 1 else "independent frames per GPU (dp%d), no data-path collective" % world},
             "roofline": roofline_block(args.config if not args.rays else "none", args.precision, n, kernel_ms, thin),
             "zero_weight": frame_stats(counters, counters["succesRays"] + counters["vignettedRays"]),
+            "target_mrays_s": round(NORTH_STAR_MRAYS_1GPU * (1.0 if world == 1 else 0.75 * world)),
         }
         if not args.no_parity:
             line["parity"] = parity_probe(cam, args.config, args.precision)
-        if not args.no_host_path:
+        if not args.no_host_path and world == 1:
             line["host_path"] = host_path_entry(cam, cfg)
     cam.close()
     torch.cuda.empty_cache()
-    if rank == 0 and not args.no_host_path:
+    if rank == 0 and not args.no_host_path and world == 1:
         line["host_path"]["per_sample"] = per_sample_latency()
 
     if not args.no_configs and world == 1:
@@ -458,56 +628,106 @@ def main():
             ents.append(config_entry(torch, cname, prec, dev, local_rank, st, wu, not args.no_parity))
         line["configs"] = ents
 
-    if not args.no_sharded:
-        # The RCCL gather of ShardedFrame has never run with peers (one GPU per lease): with more than one rank a
-        # watchdog keeps a hang in it from taking the headline (measured above, without any collective) down with it.
-        watchdog = None
-        if world > 1:
-            import threading
+    if world > 1:
+        # ---- north_star's multi-GPU number: the SAME frame, once per step, in N slabs, gather included.  Everything from here
+        # on involves transfers between GPUs that no 1-GPU lease can rehearse: a watchdog prints the line with what has been
+        # measured (the weak-scaling leg above at the least) if any of it hangs, and a failure is reported, not fatal.
+        import threading
+        strong, spf, sharded = {}, {}, []
+        weak = {"value": line["value"], "ms_per_step": line["ms_per_step"], "scaling": "weak"} if rank == 0 else None
 
-            def give_up():
-                if rank == 0:
-                    line["sharded_frame"] = "timed out after %d s (RCCL gather with peers)" % args.sharded_timeout
-                    line["notes"] = NOTES
-                    import ctypes
-                    ctypes.CDLL(None).fflush(None)
-                    print(json.dumps(line, separators=(",", ":")), flush=True)
-                os._exit(0)
-            watchdog = threading.Timer(args.sharded_timeout, give_up)
-            watchdog.daemon = True
-            watchdog.start()
-        sh = []
-        try:
-            for cname, st in (("C4", 5), ("C5", 2)):
-                e = sharded_frame_entry(torch, dist, cname, dev, rank, world, local_rank, st, args.gather_chunk_mb)
-                if rank == 0:
-                    sh.append(e)
-        except Exception as e:   # the headline must survive a failure of the gather experiment
-            if world == 1:
-                raise
-            sh.append("failed: %s" % (str(e)[:200],))
-        if watchdog is not None:
-            watchdog.cancel()
-        if rank == 0:
-            line["sharded_frame"] = sh
-
-    if dist:   # whatever the ranks' C libraries still hold (RCCL's banner) leaves before the line, so that the line comes last
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        dist.barrier(device_ids=[local_rank])
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
-        line["notes"] = NOTES
-        text = json.dumps(line, separators=(",", ":"))
-        if len(text) > 6000:     # the driver keeps the tail of the line: what explains goes first, the numbers stay
-            del line["notes"]
+        def finish_line(note=None):
+            line["weak"] = weak
+            if strong.get("with_gather"):
+                line.update(value=strong["with_gather"], ms_per_step=strong["gather_ms"], scaling="strong", compute_only=strong["compute_only"],
+                            compute_ms=strong["compute_ms"], root_ingest_gb_s=strong["root_ingest_gb_s"], root_ingest_frac=strong["root_ingest_frac"],
+                            bit_identical_to_single_gpu=strong.get("bit_identical_to_single_gpu"), sub_launches_per_slab=strong["sub_launches_per_slab"],
+                            chunk_mb=strong["chunk_mb"])
+                line["config"]["parallelism"] = "ONE frame per step in %d ray-index slabs (dp%d), RCCL gather of the 28 B/ray payload to rank 0 included" % (world, world)
+                line["config"]["rays_per_gpu_per_step"] = n // world
+            elif strong:
+                line["strong"] = strong   # the gather did not finish: value stays the weak-scaling figure and says so
+            if spf:
+                line["single_process_frame"] = spf
+            if sharded:
+                line["sharded_frame"] = sharded
+            if note:
+                line["multi_gpu_incomplete"] = note
+            line["notes"] = {k: NOTES[k] for k in ("roofline", "multi_gpu", "mode")}
             text = json.dumps(line, separators=(",", ":"))
-        if dist:   # RCCL prints its version banner through C stdio (block-buffered on a pipe): out with it before the line
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        print(text, flush=True)
+            if len(text) > 6000:
+                del line["notes"]
+                text = json.dumps(line, separators=(",", ":"))
+            flush_c_stdio()
+            print(text, flush=True)
+
+        def give_up():
+            if rank == 0:
+                finish_line("timed out after %d s behind the weak-scaling leg" % args.sharded_timeout)
+            os._exit(0)
+        watchdog = threading.Timer(args.sharded_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        note = None
+        try:
+            # rank 0 alone drives all N devices through the C-ABI (no RCCL involved); the other ranks wait on the rendezvous store,
+            # not in a collective -- a barrier kernel spinning on their GPUs would share them with rank 0's launches
+            if not args.no_single_process and not args.rays:
+                import datetime
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    try:
+                        if ndev >= world:
+                            single_process_frame_entry(torch, args.config, args.precision, list(range(world)), args.steps, args.warmup, spf)
+                        else:
+                            spf["skipped"] = "rank 0 sees %d device(s)" % ndev
+                    except Exception as e:  # noqa: BLE001
+                        spf["failed"] = str(e)[:200]
+                    store.set("zoic_spf_done", "1")
+                else:
+                    store.wait(["zoic_spf_done"], datetime.timedelta(seconds=args.sharded_timeout))
+                dist.barrier(device_ids=[local_rank])
+            if not args.rays:
+                sharded_frame_entry(torch, dist, args.config, dev, rank, world, local_rank, args.steps, args.gather_chunk_mb, args.precision, args.warmup, strong)
+            if not args.no_sharded:
+                for cname, st in (("C4", 5), ("C5", 2)):
+                    if cname != args.config:
+                        e = sharded_frame_entry(torch, dist, cname, dev, rank, world, local_rank, st, args.gather_chunk_mb)
+                        if rank == 0:
+                            sharded.append(e)
+        except Exception as e:  # noqa: BLE001 -- reported in the line; the weak leg stands
+            note = "failed: %s" % (str(e)[:200],)
+        watchdog.cancel()
+        flush_c_stdio()
+        try:
+            dist.barrier(device_ids=[local_rank])
+        except Exception:  # noqa: BLE001
+            pass
+        if rank == 0:
+            finish_line(note)
+        try:
+            dist.barrier(device_ids=[local_rank])
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        return
+
+    # ---- N = 1
+    if not args.no_sharded:
+        # north_star configs 4/5 on one GPU: nothing to gather, a slab is ONE launch (= the unsharded rates)
+        line["sharded_frame"] = [sharded_frame_entry(torch, None, cname, dev, 0, 1, local_rank, st, args.gather_chunk_mb) for cname, st in (("C4", 5), ("C5", 2))]
+    if dist:
+        flush_c_stdio()
+        dist.barrier(device_ids=[local_rank])
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
+    line["notes"] = {k: v for k, v in NOTES.items() if k != "multi_gpu"}
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > 6000:     # the driver keeps the tail of the line: what explains goes first, the numbers stay
+        del line["notes"]
+        text = json.dumps(line, separators=(",", ":"))
+    flush_c_stdio()
+    print(text, flush=True)
     if dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

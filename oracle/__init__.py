@@ -84,6 +84,7 @@ def lib():
         L.zo_lenses.argtypes = [vp]; L.zo_lenses.restype = C.POINTER(LensElement)
         L.zo_lut_keys.argtypes = [vp]; L.zo_lut_keys.restype = f32p
         L.zo_lut_boxes.argtypes = [vp]; L.zo_lut_boxes.restype = f32p
+        L.zo_surface_visits.argtypes = [vp]; L.zo_surface_visits.restype = C.c_longlong
         L.zo_counters.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.zo_bokeh_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]; L.zo_bokeh_dims.restype = C.c_int
         L.zo_bokeh_cdf_row.argtypes = [vp]; L.zo_bokeh_cdf_row.restype = f32p
@@ -223,6 +224,10 @@ class OracleCamera:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._L.zo_counters(self._h, C.byref(a), C.byref(b), C.byref(c))
         return dict(succesRays=a.value, vignettedRays=b.value, totalInternalReflection=c.value)
+
+    def surface_visits(self):
+        """Interfaces entered by traceThroughLensElements since the last lens rebuild (work measure, not a reference counter)."""
+        return int(self._L.zo_surface_visits(self._h))
 
     def bokeh_tables(self):
         x, y = C.c_int(), C.c_int()

@@ -91,6 +91,8 @@ typedef struct zo_lensdata {       /* struct Lensdata, zoic.cpp:528-541 */
     int apertureElement;
     int apertureElementSet;        /* fence for the uninitialised read, see ZO_ERR_NO_APERTURE */
     int vignettedRays, succesRays, totalInternalReflection;
+    long long surfaceVisits;       /* NOT in the reference: interfaces entered by traceThroughLensElements since the last lens
+                                      rebuild -- the work measure behind SURVEY 8(d)'s FLOP/ray (bench.py's flop_frac) */
     float apertureDistance, focalLengthRatio, filmDiagonal, originShift, focalDistance;
     float tracedFocal[2];
     int lutSize;                   /* std::map<float,boundingBox2d> as sorted arrays */
@@ -548,6 +550,7 @@ static inline int traceThroughLensElements(zo_v3 *ray_origin, zo_v3 *ray_directi
     const int n = ld->lensCount;
     for (int i = 0; i < n; i++) {
         g_probe_iface = i;
+        ld->surfaceVisits++;
         sphere_center.x = 0.0f; sphere_center.y = 0.0f; sphere_center.z = ld->lenses[i].center;
         if (!raySphereIntersection(&hit_point, *ray_direction, *ray_origin, sphere_center, ld->lenses[i].curvature, 0, 1))
             return 0;
@@ -770,7 +773,7 @@ int zo_camera_update(zo_camera *camera, const zo_params *parms)
         if (lens_changed(parms, &camera->params)) {                     /* :1615 */
             zo_lensdata *ld = &camera->lens;
             ld->lensCount = 0;                                          /* lenses.clear() */
-            ld->vignettedRays = 0; ld->succesRays = 0; ld->totalInternalReflection = 0;
+            ld->vignettedRays = 0; ld->succesRays = 0; ld->totalInternalReflection = 0; ld->surfaceVisits = 0;
             ld->originShift = 0.0; ld->lutSize = 0;
             ld->apertureElementSet = 0;
             ld->filmDiagonal = sqrtf((parms->sensorWidth * parms->sensorWidth) + (parms->sensorHeight * parms->sensorHeight));
@@ -1037,7 +1040,7 @@ void zo_create_rays(zo_camera *cam, size_t n, const float *in4, float *planes, u
     }
 }
 
-typedef struct mt_job { zo_camera *cam; size_t n; size_t *next; const float *in4; float *planes; uint8_t *flags; const uint32_t *rng; int succ, vign, tir; } mt_job;
+typedef struct mt_job { zo_camera *cam; size_t n; size_t *next; const float *in4; float *planes; uint8_t *flags; const uint32_t *rng; int succ, vign, tir; long long visits; } mt_job;
 #define ZO_MT_CHUNK 4096   /* rays a thread takes at a time: image regions differ in cost, equal slabs would leave cores idle */
 
 static void *mt_worker(void *arg)
@@ -1047,6 +1050,7 @@ static void *mt_worker(void *arg)
      * tables are shared read-only */
     zo_camera local = *j->cam;
     local.lens.succesRays = local.lens.vignettedRays = local.lens.totalInternalReflection = 0;
+    local.lens.surfaceVisits = 0;
     for (;;) {
         const size_t lo = __atomic_fetch_add(j->next, (size_t)ZO_MT_CHUNK, __ATOMIC_RELAXED);
         if (lo >= j->n) break;
@@ -1057,6 +1061,7 @@ static void *mt_worker(void *arg)
         }
     }
     j->succ = local.lens.succesRays; j->vign = local.lens.vignettedRays; j->tir = local.lens.totalInternalReflection;
+    j->visits = local.lens.surfaceVisits;
     return NULL;
 }
 
@@ -1068,7 +1073,7 @@ void zo_create_rays_mt(zo_camera *cam, size_t n, const float *in4, float *planes
     mt_job *jobs = malloc(sizeof(mt_job) * nthreads);
     size_t next = 0;
     for (int t = 0; t < nthreads; ++t) {
-        mt_job j = { cam, n, &next, in4, planes, flags, rng_states, 0, 0, 0 };
+        mt_job j = { cam, n, &next, in4, planes, flags, rng_states, 0, 0, 0, 0 };
         jobs[t] = j;
         pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
     }
@@ -1076,6 +1081,7 @@ void zo_create_rays_mt(zo_camera *cam, size_t n, const float *in4, float *planes
         pthread_join(th[t], NULL);
         cam->lens.succesRays += jobs[t].succ; cam->lens.vignettedRays += jobs[t].vign;
         cam->lens.totalInternalReflection += jobs[t].tir;
+        cam->lens.surfaceVisits += jobs[t].visits;
     }
     free(th); free(jobs);
 }
@@ -1101,6 +1107,7 @@ void  zo_counters(const zo_camera *c, int *s, int *v, int *t)
     if (v) *v = c->lens.vignettedRays;
     if (t) *t = c->lens.totalInternalReflection;
 }
+long long zo_surface_visits(const zo_camera *c) { return c->lens.surfaceVisits; }
 int   zo_bokeh_dims(const zo_camera *c, int *x, int *y) { if (x) *x = c->image.x; if (y) *y = c->image.y; return image_valid(&c->image); }
 const float *zo_bokeh_cdf_row(const zo_camera *c) { return c->image.cdfRow; }
 const float *zo_bokeh_cdf_column(const zo_camera *c) { return c->image.cdfColumn; }

@@ -118,6 +118,9 @@ float zo_aperture_distance(const zo_camera *);
 float zo_focal_length_ratio(const zo_camera *);
 float zo_traced_focal_length(const zo_camera *, int which); /* 0: before, 1: after adjust */
 int   zo_lut_size(const zo_camera *);
+/* not a reference quantity: interfaces entered by traceThroughLensElements (hot path + precompute) since the last lens rebuild;
+ * the work measure of SURVEY 8(d)'s FLOP model (~106 FLOP per interface visit + ~130 per try) */
+long long zo_surface_visits(const zo_camera *);
 const float    *zo_lut_keys(const zo_camera *);
 const zo_bbox2 *zo_lut_boxes(const zo_camera *);
 float zo_fov(const zo_camera *);

@@ -191,3 +191,48 @@ def test_two_rank_sharded_frame_through_the_hip_path(gpu, tmp_path, oracle_lib):
     ref = oc.create_rays(synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1), rng_states=ray_rng_states(n, 1, 0), threads=8)
     got = np.load(tmp_path / "payload_gpu.npy")
     assert np.array_equal(np.ascontiguousarray(got.T).view(np.uint32), ref["planes"].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------- bench.py's launcher
+def _bench():
+    sys.path.insert(0, ROOT)
+    import importlib
+    return importlib.import_module("bench")
+
+
+def test_bench_gpus_flag_means_ranks():
+    """`--gpus N` is N ranks, whoever starts them: without a launcher bench.py re-executes itself under torch.distributed.run;
+    under one it must agree with WORLD_SIZE; more ranks than GPUs is refused loudly (round 3: `--gpus 8` silently ran one rank)."""
+    import argparse
+    bench = _bench()
+    ns = lambda **kw: argparse.Namespace(**dict(dict(gpus=None, dry_launch=False), **kw))  # noqa: E731
+    assert bench.resolve_launch(ns(), {}, 1, []) == ("run", 1)
+    assert bench.resolve_launch(ns(gpus=1), {}, 8, []) == ("run", 1)
+    assert bench.resolve_launch(ns(gpus=4), {"WORLD_SIZE": "4"}, 8, []) == ("run", 4)
+    assert bench.resolve_launch(ns(), {"WORLD_SIZE": "8"}, 8, []) == ("run", 8)          # a launcher without --gpus: its world
+    what, cmd = bench.resolve_launch(ns(gpus=8), {}, 8, ["--gpus", "8", "--steps", "5"])
+    assert what == "exec" and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    for bad in (dict(a=ns(gpus=2), env={}, ndev=1),                       # a 1-GPU box asked for 2 ranks
+                dict(a=ns(gpus=2), env={"WORLD_SIZE": "4"}, ndev=8),     # --gpus contradicts the launcher
+                dict(a=ns(gpus=8), env={"WORLD_SIZE": "8"}, ndev=4),     # more ranks than devices
+                dict(a=ns(gpus=0), env={}, ndev=1)):
+        with pytest.raises(SystemExit) as e:
+            bench.resolve_launch(bad["a"], bad["env"], bad["ndev"], [])
+        assert e.value.code not in (0, None) and "bench.py" in str(e.value.code)
+
+
+def test_bench_launches_its_own_ranks_over_gloo():
+    """The real re-exec path at world 2 on CPU: `python bench.py --gpus 2 --dry-launch` (no launcher, no WORLD_SIZE) must come
+    back as two ranks that met each other; and without a GPU the measuring form exits non-zero with a clear message."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert got == {"dry_launch": True, "world": 2, "expected": 2, "sum": 2}
+    from zoic_amd import _capi
+    if _capi.load().zoic_device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "--gpus 2 but only" in (r.stdout + r.stderr)
