@@ -269,6 +269,20 @@ def roofline_block(cfg_name, precision, n, kernel_ms, thin):
     return roof
 
 
+def rank_barrier(dist, local_rank):
+    """Barrier over the ranks: RCCL wants to know the device; the gloo rehearsal (ZOIC_BENCH_SAME_GPU) does not."""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[local_rank])
+    else:
+        dist.barrier()
+
+
+def max_over_ranks(torch, dist, seconds, dev):
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_rank=0):
     """`steps` launches of one frame of n samples (resident in HBM), bracketed by barrier + synchronize on both sides.
     Returns (elapsed seconds: max over ranks, mean kernel ms by HIP events on the launch stream)."""
@@ -278,7 +292,7 @@ def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_ra
         cam.create_rays(samples, ray_index_base=base, out=out)
     torch.cuda.synchronize()
     if dist:
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
@@ -288,13 +302,11 @@ def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_ra
         ev[k][1].record()
     torch.cuda.synchronize()
     if dist:
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(torch, dist, elapsed, dev)
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(steps, 1)
     del samples, out
     return elapsed, kernel_ms
@@ -357,7 +369,7 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
             frame.run(gather=gather)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            rank_barrier(dist, local_rank)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -365,13 +377,11 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
             frame.run(gather=gather)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            rank_barrier(dist, local_rank)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el = max_over_ranks(torch, dist, el, dev)
         return el
     ent.update(config=cfg_name, mode=precision, rays=n_total, n_gpus=world, steps=steps, scaling="strong", sub_launches_per_slab=len(frame.chunks[rank]))
     t_compute = timed(False)
@@ -526,12 +536,12 @@ def resolve_launch(args, env, device_count, argv):
     if env_world is not None:
         if want != env_world:
             raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (want, env_world))
-        if not args.dry_launch and device_count < env_world:
+        if not args.dry_launch and device_count < env_world and env.get("ZOIC_BENCH_SAME_GPU") != "1":
             raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible: one rank per GPU" % (env_world, device_count))
         return "run", env_world
     if want == 1:
         return "run", 1
-    if not args.dry_launch and device_count < want:
+    if not args.dry_launch and device_count < want and env.get("ZOIC_BENCH_SAME_GPU") != "1":
         raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible on this node (one rank per GPU; nothing was measured)" % (want, device_count))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(want), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
@@ -575,6 +585,11 @@ def main():
         return dry_launch(world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ZOIC_BENCH_SAME_GPU=1: a REHEARSAL of the N > 1 control flow on a 1-GPU box -- every rank uses device 0 and the ranks meet
+    # over gloo (RCCL refuses two ranks on one device).  The line it prints is labelled and is not a measurement.
+    same_gpu = os.environ.get("ZOIC_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libzoic_amd has no CPU path")
     torch.cuda.set_device(local_rank)      # before the process group: RCCL binds the communicator to the current device
@@ -587,7 +602,10 @@ def main():
         if world == 1:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if same_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
         assert dist.get_world_size() == world, (dist.get_world_size(), world)
 
     cfg = CONFIGS[args.config]
@@ -677,8 +695,8 @@ def main():
                 store = dist.distributed_c10d._get_default_store()
                 if rank == 0:
                     try:
-                        if ndev >= world:
-                            single_process_frame_entry(torch, args.config, args.precision, list(range(world)), args.steps, args.warmup, spf)
+                        if ndev >= world or same_gpu:
+                            single_process_frame_entry(torch, args.config, args.precision, [0] * world if same_gpu else list(range(world)), args.steps, args.warmup, spf)
                         else:
                             spf["skipped"] = "rank 0 sees %d device(s)" % ndev
                     except Exception as e:  # noqa: BLE001
@@ -686,7 +704,7 @@ def main():
                     store.set("zoic_spf_done", "1")
                 else:
                     store.wait(["zoic_spf_done"], datetime.timedelta(seconds=args.sharded_timeout))
-                dist.barrier(device_ids=[local_rank])
+                rank_barrier(dist, local_rank)
             if not args.rays:
                 sharded_frame_entry(torch, dist, args.config, dev, rank, world, local_rank, args.steps, args.gather_chunk_mb, args.precision, args.warmup, strong)
             if not args.no_sharded:
@@ -700,13 +718,15 @@ def main():
         watchdog.cancel()
         flush_c_stdio()
         try:
-            dist.barrier(device_ids=[local_rank])
+            rank_barrier(dist, local_rank)
         except Exception:  # noqa: BLE001
             pass
         if rank == 0:
+            if same_gpu:
+                line["rehearsal"] = "ZOIC_BENCH_SAME_GPU=1: all %d ranks on ONE GPU over gloo -- control flow only, not a measurement" % world
             finish_line(note)
         try:
-            dist.barrier(device_ids=[local_rank])
+            rank_barrier(dist, local_rank)
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
@@ -718,7 +738,7 @@ def main():
         line["sharded_frame"] = [sharded_frame_entry(torch, None, cname, dev, 0, 1, local_rank, st, args.gather_chunk_mb) for cname, st in (("C4", 5), ("C5", 2))]
     if dist:
         flush_c_stdio()
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
     line["notes"] = {k: v for k, v in NOTES.items() if k != "multi_gpu"}
@@ -729,7 +749,7 @@ def main():
     flush_c_stdio()
     print(text, flush=True)
     if dist:
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
         dist.destroy_process_group()
 
 
