@@ -1,0 +1,423 @@
+// kolb_listed_body.hpp -- the second kernel of a decision-safe FAST launch: the rays the GUARD kernel could not decide
+// (kolb_pool_body.hpp: a clip inside an interface's guard band, in practice at the stop, which the reference traces as a sphere
+// of |R| ~ 1e4 cm -- zoic.cpp:933, 1111-1117) evaluated so that every decision is the reference's.
+//
+// Round 3 ran these rays through the STRICT pool kernel from scratch.  On the fisheye (C4) that was 14.5 % of the launch: 4.9 M
+// listed rays x 5335 lane-instructions -- a STRICT set-up, a STRICT first try, and on average 1.1 MORE tries in STRICT (a ray
+// that grazes the stop fails half of the time), although a RETRY is a fresh lens sample that lands in a guard band no more often
+// than any other (1.85 %).  The rule here -- the same for every listed ray whatever the length of the list, so that a ray's
+// bits do not depend on how a frame is cut into launches (a sharded frame equals the one-GPU frame):
+//     set-up            : the reference's arithmetic (setup_ray<true>)
+//     try 0             : the reference's arithmetic (83 % of the listed rays were listed AT their first try)
+//     try k >= 1        : FAST arithmetic with its guard bands on the STRICT set-up constants; a try with a decision inside a
+//                         guard band is evaluated again in the reference's arithmetic (same draws) and THAT result stands.
+// Every accept / reject decision is therefore either a FAST decision outside every guard band or a STRICT one -- what
+// "decision-safe" means (include/zoic_amd.h, ZOIC_PRECISION_FAST).
+//
+// Long lists (> kShortList rays; the fisheye): batches + a per-wave pool in LDS like the main kernel, with THREE kinds of pass:
+//     A  64 fresh listed rays : STRICT set-up + STRICT first try; the failures go to the pool
+//     B  64 pooled rays       : one more FAST-guarded try each (candidate search + predicated trace); a try too close to call
+//                               goes to the STRICT stack with its draws rewound
+//     C  64 rays of the STRICT stack : that try again, in the reference's arithmetic; the failures return to the pool
+// The pool and the STRICT stack share one double-ended LDS array of 192 entries per wave (B is taken first while the pool holds
+// 64, then C, then A: pool + stack never exceed 190).
+// Short lists: listed_short -- the tries of a ray side by side in the 16 lanes of a group (round 3), same rule per try.
+#pragma once
+#include "kolb_pool_body.hpp"
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace zoic {
+
+constexpr uint32_t kListedEntries = 192;                       // pool (from the bottom) + STRICT stack (from the top)
+constexpr uint32_t kListedWaveWords = kListedEntries * 12u;    // 48-byte entries, piece-major like the main kernel's pool
+
+// one try of a listed ray, k >= 1, in the reference's arithmetic: (o, d) = the state the reference leaves (zoic.cpp:1927-1947)
+__device__ __forceinline__ V3 listed_retry_direction_strict(const KolbTable &T, const BokehTables &B, const float *bokehLds, float u, float v,
+                                                            float o0x, float o0y, float maxScale, float translation, float sn, float cs)
+{
+    return retry_direction(T, lens_sample<true>(T, B, bokehLds, u, v), o0x, o0y, maxScale, translation, sn, cs);
+}
+
+// The rule above for ONE ray, sequentially (the per-sample mailbox kernel; the batch kernels below evaluate the same tries with
+// the same device functions, 64 rays or 16 tries at a time).  rng: the ray's retry stream at its first draw.
+struct ListedRay { V3 o, d; float w; uint32_t tries, lutMiss, tir; };
+__device__ __forceinline__ ListedRay listed_one_ray(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds, float4 s, Rng rng)
+{
+    ListedRay r;
+    const RaySetup rs = setup_ray<true>(T, lutLds, s.x, s.y);
+    r.lutMiss = rs.flags & 1u; r.tir = 0; r.tries = 0;
+    const V3 o0{rs.o0x, rs.o0y, T.originShift};
+    V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
+    if (!T.useLUT) r.d = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};
+    else {                                                    // zoic.cpp:1913-1924: x-only translation on the first sample
+        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
+        lens.x += rs.translation;
+        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
+        r.d = V3{rx - o0.x, ry - o0.y, T.dirZ};
+    }
+    r.o = o0;
+    bool ok = trace_lens_strict(T, r.o, r.d, r.tir);
+    while (!ok && r.tries <= static_cast<uint32_t>(kMaxTries)) {      // zoic.cpp:1927
+        const float u = rng_unit(xor128(rng));                        // zoic.cpp:1930
+        const float v = rng_unit(xor128(rng));
+        ++r.tries;
+        r.o = o0;
+        r.d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+        uint32_t tirTry = 0;
+        bool unsure = false;
+        ok = trace_lens_fast_rolled(T, r.o, r.d, tirTry, &unsure);
+        if (unsure) {
+            r.o = o0; tirTry = 0;
+            r.d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+            ok = trace_lens_strict(T, r.o, r.d, tirTry);
+        }
+        r.tir += tirTry;
+    }
+    r.w = (r.tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;   // zoic.cpp:1951-1957: try 26 hands out its state with weight 0 whatever it did
+    if (T.exposureOn) r.w *= T.exposureMul;                             // zoic.cpp:1981-1987
+    return r;
+}
+
+// Short lists: G = 16 tries of a ray side by side (round 3's listed_short; the rule per try is the one above).  The tries of a
+// ray are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1); the first success in try order wins and
+// TIR bumps count for the tries before it only (try 26 hands out its state with weight 0 whether it got through or not,
+// zoic.cpp:1927 / 1951).
+__device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
+                                                    const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63u, j = lane % kShortGroup, g = lane / kShortGroup;
+    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock, waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t *list = ZOIC_KARG(redoList);
+    const uint4 *states = ZOIC_KARG(rngStates);
+    const uint64_t rayBase = ZOIC_KARG(rayBase);
+    uint32_t succ = 0, vign = 0, tir = 0;   // per lane; reduced at the end
+    for (uint32_t first = waveId * kShortRaysPerWave; first < n; first += wavesTotal * kShortRaysPerWave) {
+        const uint32_t li = first + g;
+        const bool have = li < n;
+        const uint32_t idx = list[have ? li : n - 1u];
+        const float4 s = samples[idx];
+        const RaySetup rs = setup_ray<true>(T, lutLds, s.x, s.y);
+        const V3 o0{rs.o0x, rs.o0y, T.originShift};
+        Rng rng;
+        if (states) { const uint4 q = states[idx]; rng = Rng{q.x, q.y, q.z, q.w}; }
+        else rng = rng_for_ray(T.seed, rayBase + idx);
+        for (uint32_t a = 1; a < j; ++a) { (void)xor128(rng); (void)xor128(rng); }   // lane j >= 1 starts at draw 2 (j - 1)
+        bool done = !have;
+        for (uint32_t round = 0; round * kShortGroup <= static_cast<uint32_t>(kMaxTries) + 1u; ++round) {
+            const uint32_t k = kShortGroup * round + j;                      // this lane's try: 0 = the sample's own lens point, k = tries
+            const bool valid = !done && k <= static_cast<uint32_t>(kMaxTries) + 1u;
+            V3 o = o0, d{0.0f, 0.0f, 1.0f};
+            uint32_t tirTry = 0;
+            bool ok = false;
+            if (valid) {
+                if (k == 0u) {
+                    V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
+                    if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+                    else {                                                    // zoic.cpp:1913-1924: x-only translation
+                        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
+                        lens.x += rs.translation;
+                        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
+                        d = V3{rx - o.x, ry - o.y, T.dirZ};
+                    }
+                    ok = trace_lens_strict(T, o, d, tirTry);
+                } else {
+                    const float u = rng_unit(xor128(rng));                    // zoic.cpp:1930
+                    const float v = rng_unit(xor128(rng));
+                    d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+                    bool unsure = false;
+                    ok = trace_lens_fast_rolled(T, o, d, tirTry, &unsure);
+                    if (unsure) {   // too close to call: this try in the reference's arithmetic
+                        o = o0; tirTry = 0;
+                        d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+                        ok = trace_lens_strict(T, o, d, tirTry);
+                    }
+                }
+            }
+            // the next try of this lane, k + G, starts at draw 2 (k + G - 1): G - 1 pairs past where this try ended (2 k; try 0 drew nothing)
+            for (uint32_t a = 0; a + 1u < kShortGroup; ++a) { (void)xor128(rng); (void)xor128(rng); }
+            // the group's decision, in try order
+            const unsigned long long okAll = __ballot(valid && ok);
+            const uint32_t okGroup = static_cast<uint32_t>(okAll >> (kShortGroup * g)) & ((1u << kShortGroup) - 1u);
+            const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : kShortGroup;   // lowest try that got through
+            if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
+            const bool last = k == static_cast<uint32_t>(kMaxTries) + 1u;      // try 26 failed as well: weight 0, ITS partial state
+            if (valid && (j == winner || (winner == kShortGroup && last))) {
+                const bool okRay = j == winner && !last;
+                float w = okRay ? 1.0f : 0.0f;
+                if (T.exposureOn) w *= T.exposureMul;                          // zoic.cpp:1981-1987
+                store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
+                                 (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6));
+                if (okRay) ++succ; else ++vign;
+            }
+            done = done || winner != kShortGroup || kShortGroup * (round + 1u) > static_cast<uint32_t>(kMaxTries) + 1u;
+            if (__ballot(!done) == 0ull) break;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { succ += __shfl_xor(succ, off, 64); vign += __shfl_xor(vign, off, 64); tir += __shfl_xor(tir, off, 64); }
+    DeviceCounters *counters = counter_set(ZOIC_KARG(counters));
+    if (counters && lane == 0) {
+        if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
+        if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
+        if (tir) atomicAdd(&counters->tir, static_cast<unsigned long long>(tir));
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
+                                                 RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching)
+{
+    constexpr uint32_t kOut = static_cast<uint32_t>(kMaxTries) + 1u;   // tries of a ray that ran out (zoic.cpp:1927: tries <= 25)
+    const uint32_t n = *ZOIC_KARG(redoCount);   // the work list's length is only known on the device
+    if (n == 0u) return;
+    // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times over
+    const uint32_t redoChunk = n > (1u << 20) ? 256u : 64u;
+    const uint32_t totalChunks = n <= kShortList ? (n + kShortRaysPerWave - 1u) / kShortRaysPerWave : (n + redoChunk - 1u) / redoChunk;
+    if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed for it
+    const uint32_t redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < kLutEntries) {
+        zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
+        zoicDynLds[2 * threadIdx.x + 1] = T.lutCentroidX[threadIdx.x];
+    }
+    const float *bokehLds = nullptr;
+    if (ldsWords > 0) {
+        for (uint32_t i = threadIdx.x; i < ldsWords; i += kRefillBlock) zoicDynLds[kLutLdsWords + i] = __builtin_bit_cast(float, B.rowCells[i]);
+        bokehLds = zoicDynLds + kLutLdsWords;
+    }
+    __syncthreads();
+    const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
+    if (n <= kShortList) { listed_short_hybrid(T, B, lutLds, bokehLds, samples, n, out); return; }
+
+    // the double-ended array: pool entries 0 .. poolCnt-1, STRICT stack entries kListedEntries-1 downwards
+    float4 *pool0 = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords + wave * kListedWaveWords);   // idx, o0x, o0y, packed
+    uint4 *pool2 = reinterpret_cast<uint4 *>(pool0 + kListedEntries);                                             // the ray's retry stream
+    float4 *pool1 = reinterpret_cast<float4 *>(pool2 + kListedEntries);                                           // maxScale, translation, sn, cs
+    uint32_t poolCnt = 0, stackCnt = 0;   // wave-uniform
+
+    uint32_t next = 0, end = 0, part = blockIdx.x % kCursorParts, partsTried = 0;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    uint32_t idx1 = 0, idx2 = 0, cnt1 = 0, cnt2 = 0;
+    bool have1 = false, have2 = false;
+    const auto request_batch = [&]() {   // -> b2
+        have2 = false;
+        if (next >= end) {
+            if (!claim_chunk(ZOIC_KARG(workCursor), lane, part, partsTried, redoChunk, redoChunksPerPart, n, next, end)) return;
+        }
+        cnt2 = (end - next < 64u) ? end - next : 64u;
+        const uint32_t wi = (lane < cnt2) ? next + lane : next;
+        idx2 = ZOIC_KARG(redoList)[wi];
+        s2 = samples[idx2];
+        next += cnt2;
+        have2 = true;
+    };
+    const auto advance_batches = [&]() {
+        s1 = s2; idx1 = idx2; cnt1 = cnt2; have1 = have2;
+        if (have1) request_batch();
+    };
+    request_batch();
+    advance_batches();
+
+    uint32_t succ = 0, vign = 0, tir = 0;   // wave totals (SGPRs): no ray leaves this kernel unfinished, TIR bumps count as they happen
+    for (;;) {
+        const bool drain = !have1;
+        // B while the pool holds a full batch, then C, then fresh work; without fresh work whatever is left, pool first
+        const bool passB = poolCnt >= 64u || (drain && poolCnt != 0u);
+        const bool passC = !passB && (stackCnt >= 64u || (drain && stackCnt != 0u));
+        if (!passB && !passC && drain) break;
+        const bool strictPass = !passB;   // A and C run the reference's arithmetic
+
+        bool active, dead = false, unsure = false, cand = false, searching = false, finiteSample = true;
+        uint32_t idx, tries, lutMiss;
+        float o0x, o0y, maxScale, translation, sn, cs;
+        Rng rng{1, 2, 3, 4}, rngBefore{1, 2, 3, 4};
+        V3 o, d{0.0f, 0.0f, 1.0f};
+        const auto clears_rear_strict = [&](const V3 &oo, const V3 &dd) {
+            bool inRange;
+            bool p = interface0_clear_strict_lean(T, oo, dd, inRange);
+            if (__builtin_expect(!inRange, 0)) p = interface0_clear_strict(T, oo, dd);   // never seen: guarded roots
+            return p;
+        };
+        if (!passB && !passC) {
+            // ---- A: 64 fresh listed rays, the reference's set-up and first try (zoic.cpp:1853-1925) ----------------------------
+            active = lane < cnt1;
+            idx = idx1;
+            const RaySetup rs = setup_ray<true>(T, lutLds, s1.x, s1.y);
+            o0x = rs.o0x; o0y = rs.o0y; maxScale = rs.maxScale; translation = rs.translation; sn = rs.sn; cs = rs.cs;
+            lutMiss = rs.flags & 1u; dead = rs.dead;
+            tries = 0;
+            o = V3{o0x, o0y, T.originShift};
+            const float u = s1.z, v = s1.w;
+            V2 lens = lens_sample<true>(T, B, bokehLds, u, v);
+            if (__ballot(dead) != 0ull) {   // dead pixel (outside the image circle, LUT entries zero): all 27 tries are this one (kolb_pool_body.hpp)
+                const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
+                if (dead && plainSample) lens = V2{0.0f, 0.0f};
+                finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
+            }
+            if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+            else {
+                lens.x *= maxScale; lens.y *= maxScale;
+                lens.x += translation;
+                const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
+                d = V3{rx - o.x, ry - o.y, T.dirZ};
+            }
+            cand = active && clears_rear_strict(o, d);
+            advance_batches();
+        } else {
+            // ---- B / C: 64 rays from the pool / the STRICT stack -------------------------------------------------------------
+            uint32_t cnt, slotBase;
+            if (passB) { cnt = poolCnt < 64u ? poolCnt : 64u; poolCnt -= cnt; slotBase = poolCnt; }
+            else { cnt = stackCnt < 64u ? stackCnt : 64u; stackCnt -= cnt; slotBase = kListedEntries - stackCnt - cnt; }
+            active = lane < cnt;
+            const uint32_t slot = slotBase + (active ? lane : 0u);
+            const float4 e0 = pool0[slot];
+            const uint4 e2 = pool2[slot];
+            const float4 e1 = pool1[slot];
+            const uint32_t packed = __builtin_bit_cast(uint32_t, e0.w);
+            idx = __builtin_bit_cast(uint32_t, e0.x); o0x = e0.y; o0y = e0.z;
+            maxScale = e1.x; translation = e1.y; sn = e1.z; cs = e1.w;
+            rng = Rng{e2.x, e2.y, e2.z, e2.w};
+            tries = (packed >> kPoolTriesShift) & 31u;
+            lutMiss = packed & 1u;
+            o = V3{o0x, o0y, T.originShift};
+            if (passC) {
+                // the try that was too close to call, again, in the reference's arithmetic: same draws (the stack holds the stream
+                // BEFORE them and the try count before its increment)
+                const float u = rng_unit(xor128(rng));                        // zoic.cpp:1930
+                const float v = rng_unit(xor128(rng));
+                ++tries;
+                d = listed_retry_direction_strict(T, B, bokehLds, u, v, o0x, o0y, maxScale, translation, sn, cs);
+                cand = active && clears_rear_strict(o, d);
+            } else {
+                // candidate search in FAST arithmetic with the guard band of interface 0 (kolb_pool_body.hpp): a lane keeps drawing
+                // while enough lanes are looking; tries and the retry stream advance exactly as in the reference's loop
+                const FastSurfaceTable fsurf = kernarg_fast_surfaces();
+                searching = active;
+                for (;;) {
+                    const uint32_t looking = static_cast<uint32_t>(__popcll(__ballot(searching)));
+                    if (looking < (drain ? 1u : minSearching)) break;
+                    if (searching) {
+                        if (tries == 0) {               // first retry of this ray: seed its private xorshift128 stream
+                            const uint4 *states = ZOIC_KARG(rngStates);
+                            if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+                            else rng = rng_for_ray(kernarg_field<uint32_t, offsetof(KolbKernelArgs, T) + offsetof(KolbTable, seed)>(), ZOIC_KARG(rayBase) + idx);
+                        }
+                        rngBefore = rng;
+                        const float u = rng_unit(xor128(rng));   // zoic.cpp:1930
+                        const float v = rng_unit(xor128(rng));
+                        ++tries;
+                        d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), o0x, o0y, maxScale, translation, sn, cs);
+                        bool near0;
+                        const bool pass0 = interface0_clear_fast<true>(load_surface<false>(fsurf, 0), o, d, near0);
+                        if (near0) { unsure = true; searching = false; }
+                        else if (pass0) { cand = true; searching = false; }
+                        else if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
+                    }
+                }
+            }
+        }
+
+        // ---- one full trace for every lane that holds a candidate --------------------------------------------------------------
+        bool ok = false;
+        const V3 oStart = o, dStart = d;
+        const unsigned long long candMask = __ballot(cand);
+        if (candMask != 0ull) {
+            uint32_t tirTry = 0;
+            if (strictPass) {
+                if constexpr (NS > 0) {
+                    bool oor = false;
+                    ok = trace_lens_strict_pred<NS>(T, o, d, tirTry, cand, oor);
+                    if (__builtin_expect(__ballot(cand && oor) != 0ull, 0)) {   // never seen: a root left the lean sequences' verified range
+                        if (cand && oor) { o = oStart; d = dStart; tirTry = 0; ok = trace_lens_strict(T, o, d, tirTry); }
+                    }
+                } else if (cand) ok = trace_lens_strict(T, o, d, tirTry);
+            } else {
+                if constexpr (NS > 0) {
+                    unsigned long long tirMask, unsureMask;
+                    const unsigned long long alive = trace_lens_fast_pred<NS, true>(kernarg_fast_surfaces(), o, d, candMask, tirMask, unsureMask);
+                    ok = mask_bit(alive, lane);
+                    tirTry = mask_bit(tirMask, lane) ? 1u : 0u;
+                    unsure |= mask_bit(unsureMask, lane);
+                } else if (cand) { bool u2 = false; ok = trace_lens_fast_rolled(T, o, d, tirTry, &u2); unsure |= u2; }
+            }
+            // a dead pixel's 26 retries repeat its first try bit for bit (the retry direction of lens = (0,0) is the first try's)
+            const bool shortcut = cand && !ok && tries == 0u && dead && finiteSample;
+            // TIR bumps count for the tries this pass DECIDED (a try on its way to the STRICT stack is counted there)
+            tir += static_cast<uint32_t>(__popcll(__ballot(tirTry != 0u && !unsure))) + kOut * static_cast<uint32_t>(__popcll(__ballot(shortcut && tirTry != 0u)));
+            if (shortcut) tries = kOut;
+            if constexpr (NS > 0) {
+                // the predicated traces do not keep the partial state of a failed ray; a ray that FINISHES failed gets it from the
+                // branchy trace of the arithmetic that decided it
+                if (cand && !ok && tries > static_cast<uint32_t>(kMaxTries) && !unsure) {
+                    uint32_t ignored = 0;
+                    o = oStart; d = dStart;
+                    if (strictPass) (void)trace_lens_strict(T, o, d, ignored);
+                    else (void)trace_lens_fast_rolled(T, o, d, ignored);
+                }
+            }
+        }
+        // A: a dead pixel whose first try died at interface 0 (no trace): all 27 tries are that one
+        if (!passB && !passC && active && !cand && dead && finiteSample) tries = kOut;
+        if (!cand) { o = oStart; d = dStart; }   // a lane that ran out at interface 0 hands out the untouched (o, d) of its last sample
+
+        // ---- finished rays; the rest goes to the pool, a try too close to call to the STRICT stack -----------------------------
+        const bool toStack = active && unsure;
+        const bool finished = active && !searching && !unsure && (ok || tries > static_cast<uint32_t>(kMaxTries));
+        {
+            const uint32_t nv = static_cast<uint32_t>(__popcll(__ballot(finished && tries > static_cast<uint32_t>(kMaxTries))));
+            vign += nv;                                                                       // zoic.cpp:1951-1957
+            succ += static_cast<uint32_t>(__popcll(__ballot(finished))) - nv;
+        }
+        if (finished) {
+            float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;
+            if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
+            store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
+                             (tries > 0 ? 1u : 0u) | (tries << 1) | ((lutMiss & 1u) << 6));
+        }
+        {
+            const unsigned long long m = __ballot(toStack);
+            if (m != 0ull) {
+                if (toStack) {   // rewound: the stream before this try's draws, the try count before its increment
+                    const uint32_t slot = kListedEntries - 1u - (stackCnt + mask_rank(m));
+                    const uint32_t packed = (lutMiss & 1u) | ((tries - 1u) << kPoolTriesShift);
+                    pool0[slot] = make_float4(__builtin_bit_cast(float, idx), o0x, o0y, __builtin_bit_cast(float, packed));
+                    pool1[slot] = make_float4(maxScale, translation, sn, cs);
+                    pool2[slot] = make_uint4(rngBefore.x, rngBefore.y, rngBefore.z, rngBefore.w);
+                }
+                stackCnt += static_cast<uint32_t>(__popcll(m));
+            }
+        }
+        {
+            const bool keep = active && !finished && !toStack;
+            const unsigned long long m = __ballot(keep);
+            if (m != 0ull) {
+                if (keep) {
+                    const uint32_t slot = poolCnt + mask_rank(m);
+                    const uint32_t packed = (lutMiss & 1u) | (tries << kPoolTriesShift);
+                    pool0[slot] = make_float4(__builtin_bit_cast(float, idx), o0x, o0y, __builtin_bit_cast(float, packed));
+                    pool1[slot] = make_float4(maxScale, translation, sn, cs);
+                    if (tries != 0u) pool2[slot] = make_uint4(rng.x, rng.y, rng.z, rng.w);   // a ray that has not drawn yet is seeded when it is popped
+                }
+                poolCnt += static_cast<uint32_t>(__popcll(m));
+            }
+        }
+    }
+    DeviceCounters *counters = counter_set(ZOIC_KARG(counters));
+    if (counters && lane == 0) {
+        if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
+        if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
+        if (tir) atomicAdd(&counters->tir, static_cast<unsigned long long>(tir));
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(kRefillBlock) ZOIC_POOL_ATTR_STRICT void kolb_listed_kernel(
+    const KolbTable T, const BokehTables B, const float4 *__restrict__ samples, const uint4 *__restrict__ rngStates, uint64_t rayBase, uint32_t n,
+    RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor, uint32_t ldsWords, uint32_t chunkRays,
+    uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList, unsigned int *__restrict__ redoCount,
+    unsigned int *__restrict__ clearCursor)
+{
+    kolb_listed_body<NS>(T, B, samples, out, ldsWords, minSearching);
+}
+
+}  // namespace zoic

@@ -788,11 +788,14 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         kolb_pool_body<STRICT_, NS, GUARD_, LISTED_, DEAD, IMAGE>(T, B, samples, n, out, ldsWords, minSearching);             \
     }
 ZOIC_POOL_KERNEL(kolb_pool_strict_kernel, ZOIC_POOL_ATTR_STRICT, true, false, false)          // STRICT, whole batch
-ZOIC_POOL_KERNEL(kolb_pool_strict_listed_kernel, ZOIC_POOL_ATTR_STRICT, true, false, true)    // STRICT over the work list of the GUARD kernel
 ZOIC_POOL_KERNEL(kolb_pool_fast_kernel, ZOIC_POOL_ATTR_FAST, false, false, false)             // FAST unchecked
 ZOIC_POOL_KERNEL(kolb_pool_guard_kernel, ZOIC_POOL_ATTR_FAST, false, true, false)             // FAST decision-safe
 #undef ZOIC_POOL_KERNEL
 #undef ZOIC_POOL_PARAMS
+
+int launch_kolb_listed(const KolbTable &table, const BokehTables &bokeh, const float4 *d_samples, const uint4 *d_rng, uint64_t rayBase, uint32_t m,
+                       RayRecord *out, DeviceCounters *d_counters, unsigned int *d_redoCursor, uint32_t *d_redoList, unsigned int *d_redoCount,
+                       unsigned grid, void *stream);   // kolb_listed.hip
 
 // mode: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked.  d_scratch: the work list of mode 1 (kolb_scratch_dwords():
 // one dword per sample of a launch)
@@ -841,8 +844,10 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
             ZOIC_LAUNCH_POOL_BY_COUNT(kolb_pool_guard_kernel, d_workCursor, true)
             e = hipGetLastError();
             if (e != hipSuccess) return static_cast<int>(e);
-            // the rays it listed, in the reference's arithmetic; workgroups beyond the list's length retire at once
-            ZOIC_LAUNCH_POOL_BY_COUNT(kolb_pool_strict_listed_kernel, redoCursor, false)
+            // the rays it listed (kolb_listed_body.hpp): the reference's arithmetic where a decision is too close to call;
+            // workgroups beyond the list's length retire at once
+            e = static_cast<hipError_t>(launch_kolb_listed(table, bokeh, sp, rp, rayBase + done, static_cast<uint32_t>(m), o, d_counters, redoCursor,
+                                                           d_redoList, redoCount, grid, stream));
         }
 #undef ZOIC_LAUNCH_POOL_BY_COUNT
 #undef ZOIC_LAUNCH_POOL

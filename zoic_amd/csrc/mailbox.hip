@@ -9,7 +9,7 @@
 //     its first word, written last) and spins on the slot's REPLY;
 //   * the wave polls its request with three global_load_dwordx4 across PCIe (host memory is mapped uncached on the GPU:
 //     every poll sees memory); when the three chunks carry one NEW sequence number it evaluates the ray -- the reference's own loop, one ray per lane, STRICT or FAST arithmetic (optics.hpp /
-//     fast_optics.hpp; a FAST ray with a decision inside its guard band is re-evaluated in STRICT on the spot) -- bumps the
+//     fast_optics.hpp; a FAST ray with a decision inside a guard band is re-evaluated on the spot by the listed kernel's rule, kolb_listed_body.hpp) -- bumps the
 //     camera's counters and writes the REPLY: three 16-byte chunks, sequence number last.  A chunk is one PCIe
 //     transaction: torn reads are impossible within a chunk and detected across chunks (all three numbers must agree), so
 //     no fences or doorbells are needed in either direction;
@@ -21,7 +21,7 @@
 // nothing to gain from the fast variant -- so under ZOIC_PRECISION_FAST with optical vignetting on, where the batch path runs
 // thin_refill.hip's fast arithmetic, a per-sample ray and a batch ray of the same sample can differ in low-order bits (never in
 // a decision: the fast vignetting test is decision-safe).  include/zoic_amd.h states this at zoic_camera_create_ray.
-#include "kolb_pool_body.hpp"   // setup_ray, retry_direction (+ kolb_device.hpp: lens_sample, the traces, zoicDynLds)
+#include "kolb_listed_body.hpp"   // listed_one_ray; kolb_pool_body.hpp: setup_ray, retry_direction (+ kolb_device.hpp: lens_sample, the traces, zoicDynLds)
 #include "mailbox.hpp"
 #include "thin_device.hpp"
 
@@ -156,7 +156,10 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                     if (mode == 0) r = kolb_one_ray<true>(T, B, lutLds, bokehLds, s, rng, false);
                     else {
                         r = kolb_one_ray<false>(T, B, lutLds, bokehLds, s, rng, mode == 1);
-                        if (r.unsure) r = kolb_one_ray<true>(T, B, lutLds, bokehLds, s, rng, false);   // too close to call: the reference's arithmetic decides
+                        if (r.unsure) {   // a decision too close to call: the ray is evaluated as the batch path's listed kernel does it
+                            const ListedRay q = listed_one_ray(T, B, lutLds, bokehLds, s, rng);   // (kolb_listed_body.hpp: same rule, same bits)
+                            r.o = q.o; r.d = q.d; r.w = q.w; r.tries = q.tries; r.lutMiss = q.lutMiss; r.tir = q.tir;
+                        }
                     }
                     o = V3{r.o.x * -1.0f, r.o.y * -1.0f, r.o.z * -1.0f}; d = V3{r.d.x * -1.0f, r.d.y * -1.0f, r.d.z * -1.0f};   // zoic.cpp:1960-1961
                     w = r.w; tries = r.tries; lutMiss = r.lutMiss; tir += r.tir;
