@@ -1,6 +1,10 @@
 // fast_optics.hpp -- FAST-mode device arithmetic of the Kolb path (gfx950).  Same algorithm and the same
 // accept/reject formulas as optics.hpp (zoic.cpp:973-1158, 1850-1948), re-associated for the VALU:
-//   * f32 only (the reference's f64 intermediates dropped), FMA contraction on;
+//   * f32 only (the reference's f64 intermediates dropped), with EXPLICIT fused multiply-adds (ffma below) and contraction OFF:
+//     every rounding of the FAST arithmetic is written in this file.  (Rounds 1-3 let the compiler contract -- `fp contract(fast)`
+//     -- and the same source then rounded differently in the rolled trace, the unrolled trace and in each kernel it was inlined
+//     into: 0.7 % of the rays differed in their last bits between two code paths, which a ray that may be evaluated by either
+//     of two kernels -- kolb_listed_body.hpp -- cannot afford: SURVEY 8e wants a sharded frame bit-identical to the one-GPU frame.)
 //   * the ray direction is normalised once (v_rsq_f32) and then stays unit by construction -- the reference
 //     re-normalises it at every surface and twice more inside Snell (zoic.cpp:974,1002,1009-1010);
 //   * the surface normal is (centre - hit) * (1/R): |centre - hit| == |R| on the sphere, no sqrt;
@@ -16,10 +20,11 @@
 
 #include "optics.hpp"
 
-#pragma clang fp contract(fast)
+#pragma clang fp contract(off)
 
 namespace zoic {
 
+__device__ __forceinline__ float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }   // one v_fma_f32, one rounding
 __device__ __forceinline__ float fsqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float frsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_sin_f32(float x) { return parabola_sin(wrap_to_pi(x)); }
@@ -30,7 +35,7 @@ __device__ __forceinline__ float frcp_fast(float x) { return __builtin_amdgcn_rc
 // concentricDiskSample (zoic.cpp:686-704) with one v_rcp_f32 instead of an IEEE divide; branch-free
 __device__ __forceinline__ V2 concentric_disk_f32(float ox, float oy)
 {
-    const float a = 2.0f * ox - 1.0f, b = 2.0f * oy - 1.0f;
+    const float a = ffma(2.0f, ox, -1.0f), b = ffma(2.0f, oy, -1.0f);
     const bool wide = (a * a) > (b * b);
     const float num = wide ? b : a, den = wide ? a : b;
     const float q = 0.78539816339f * (num * frcp_fast(den));   // 0/0 -> NaN like the reference
@@ -48,13 +53,13 @@ __device__ __forceinline__ float atan2_f32(float y, float x)
     const float s = t * t;
     // atan(t)/t on [0,1], degree-7 in s (Abramowitz-Stegun style minimax, max error ~1e-7)
     float p = -0.0040540580f;
-    p = p * s + 0.0218612288f;
-    p = p * s - 0.0559098861f;
-    p = p * s + 0.0964200441f;
-    p = p * s - 0.1390853351f;
-    p = p * s + 0.1994653599f;
-    p = p * s - 0.3332985605f;
-    p = p * s + 0.9999993329f;
+    p = ffma(p, s, 0.0218612288f);
+    p = ffma(p, s, -0.0559098861f);
+    p = ffma(p, s, 0.0964200441f);
+    p = ffma(p, s, -0.1390853351f);
+    p = ffma(p, s, 0.1994653599f);
+    p = ffma(p, s, -0.3332985605f);
+    p = ffma(p, s, 0.9999993329f);
     float r = p * t;
     r = (ay > ax) ? kPiOver2 - r : r;
     r = (x < 0.0f) ? kPi - r : r;
@@ -133,13 +138,15 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
 //
 // FastHit: the arithmetic of ONE interface, shared by the predicated trace, the branchy trace and the interface-0 test, so that
 // the three agree bit for bit on every decision.
+__device__ __forceinline__ float fast_norm2(const V3 &d) { return ffma(d.z, d.z, ffma(d.y, d.y, d.x * d.x)); }
+__device__ __forceinline__ float fast_axis2(const V3 &o) { return ffma(o.y, o.y, o.x * o.x); }
 struct FastHit { float w, thc, h2, tca; V3 hit; };
 __device__ __forceinline__ FastHit fast_hit(const FastSurface &S, const V3 &o, float oAxis2, const V3 &u)
 {
     FastHit r;
     const float Lz = S.center - o.z;
-    const float tca = Lz * u.z - o.x * u.x - o.y * u.y;
-    const float d2 = (oAxis2 + Lz * Lz) - tca * tca;
+    const float tca = ffma(-o.y, u.y, ffma(Lz, u.z, -(o.x * u.x)));     // L.u with L = (-o.x, -o.y, Lz)
+    const float d2 = ffma(-tca, tca, ffma(Lz, Lz, oAxis2));             // |L|^2 - tca^2, |L|^2 = h^2 of the previous hit + Lz^2
     r.tca = tca;
     // A ray that MISSES the sphere (d2 > radius2, zoic.cpp:981) takes the root of a negative number: thc, the hit point and h^2
     // are NaN, and every clip test below is written !(h2 <= limit) -- true for NaN -- so the miss needs no compare of its own.
@@ -147,9 +154,9 @@ __device__ __forceinline__ FastHit fast_hit(const FastSurface &S, const V3 &o, f
     // reference and comes out a NaN success; it is recognised by its NaN tca at the first interface, is_nan_ray.)
     r.w = S.radius2 - d2;                                   // thc^2
     r.thc = fsqrt_fast(r.w);
-    const float t = tca + r.thc * S.sign;
-    r.hit = V3{o.x + u.x * t, o.y + u.y * t, o.z + u.z * t};
-    r.h2 = r.hit.x * r.hit.x + r.hit.y * r.hit.y;
+    const float t = ffma(r.thc, S.sign, tca);
+    r.hit = V3{ffma(u.x, t, o.x), ffma(u.y, t, o.y), ffma(u.z, t, o.z)};
+    r.h2 = ffma(r.hit.y, r.hit.y, r.hit.x * r.hit.x);
     return r;
 }
 __device__ __forceinline__ bool is_nan_ray(const FastHit &h) { return h.tca != h.tca; }
@@ -159,7 +166,7 @@ __device__ __forceinline__ float fast_refract(const FastSurface &S, const FastHi
 {
     const float q = h.w + S.qOffset;
     const float kr = (h.thc - fsqrt_fast(fabsf(q))) * S.krScale;
-    u = V3{u.x * S.eta - h.hit.x * kr, u.y * S.eta - h.hit.y * kr, u.z * S.eta + (S.center - h.hit.z) * kr};
+    u = V3{ffma(u.x, S.eta, -(h.hit.x * kr)), ffma(u.y, S.eta, -(h.hit.y * kr)), ffma(S.center - h.hit.z, kr, u.z * S.eta)};
     return q;
 }
 
@@ -189,9 +196,9 @@ __device__ __forceinline__ int fast_interface(const FastSurface &S, V3 &o, float
 template <bool GUARD>
 __device__ __forceinline__ bool interface0_clear_fast(const FastSurface &S, V3 o, V3 d, bool &near)
 {
-    const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
+    const float inv = frsq_fast(fast_norm2(d));
     const V3 u{d.x * inv, d.y * inv, d.z * inv};
-    const FastHit h = fast_hit(S, o, o.x * o.x + o.y * o.y, u);
+    const FastHit h = fast_hit(S, o, fast_axis2(o), u);
     if constexpr (GUARD) {
         const bool insideLo = h.h2 <= S.housingLo;           // false for a sphere miss (NaN)
         near = !insideLo & (h.h2 <= S.housingHi);
@@ -206,9 +213,9 @@ __device__ __forceinline__ bool interface0_clear_fast(const FastSurface &S, V3 o
 // path, so it is also what finishes rays that ran out of tries in the predicated kernel below.
 __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool *unsure = nullptr)
 {
-    const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
+    const float inv = frsq_fast(fast_norm2(d));
     V3 u{d.x * inv, d.y * inv, d.z * inv};
-    float oAxis2 = o.x * o.x + o.y * o.y;
+    float oAxis2 = fast_axis2(o);
     bool ok = true, refracted = false;
     const int n = T.lensCount;
     // Every lane still in the loop is at the same surface, but the divergent exits hide that from the compiler;
@@ -245,9 +252,9 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
                                                                    unsigned long long &tirMask, unsigned long long &unsureMask)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
-    const float inv = frsq_fast(d.x * d.x + d.y * d.y + d.z * d.z);
+    const float inv = frsq_fast(fast_norm2(d));
     V3 u{d.x * inv, d.y * inv, d.z * inv};
-    float oAxis2 = o.x * o.x + o.y * o.y;
+    float oAxis2 = fast_axis2(o);
     unsigned long long alive = alive0, tirSeen = 0ull, unsure = 0ull;   // alive0: lanes without a candidate ride along dead
     unsigned long long nanRays = 0ull;                                  // candidates that arrived as NaN: they "pass" everything
     // The table words of interface i + 1 are requested BEFORE interface i is evaluated (scalar loads return out of order, so

@@ -83,6 +83,7 @@ __device__ __forceinline__ ListedRay listed_one_ray(const KolbTable &T, const Bo
 // ray are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1); the first success in try order wins and
 // TIR bumps count for the tries before it only (try 26 hands out its state with weight 0 whether it got through or not,
 // zoic.cpp:1927 / 1951).
+template <int NS>
 __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
                                                     const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out)
 {
@@ -109,7 +110,11 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
             const bool valid = !done && k <= static_cast<uint32_t>(kMaxTries) + 1u;
             V3 o = o0, d{0.0f, 0.0f, 1.0f};
             uint32_t tirTry = 0;
-            bool ok = false;
+            bool ok = false, unsure = false;
+            float u = 0.0f, v = 0.0f;
+            // every lane's direction first; then ONE FAST-guarded trace for the tries k >= 1 of the whole wave -- the predicated trace of
+            // the long-list path, so that a ray's bits do not depend on the path (the rolled trace contracts its FMAs differently) --
+            // and the reference's arithmetic for try 0 and for the tries that were too close to call
             if (valid) {
                 if (k == 0u) {
                     V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
@@ -120,19 +125,37 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
                         const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
                         d = V3{rx - o.x, ry - o.y, T.dirZ};
                     }
-                    ok = trace_lens_strict(T, o, d, tirTry);
                 } else {
-                    const float u = rng_unit(xor128(rng));                    // zoic.cpp:1930
-                    const float v = rng_unit(xor128(rng));
+                    u = rng_unit(xor128(rng));                                // zoic.cpp:1930
+                    v = rng_unit(xor128(rng));
                     d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-                    bool unsure = false;
-                    ok = trace_lens_fast_rolled(T, o, d, tirTry, &unsure);
-                    if (unsure) {   // too close to call: this try in the reference's arithmetic
-                        o = o0; tirTry = 0;
-                        d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-                        ok = trace_lens_strict(T, o, d, tirTry);
+                }
+            }
+            const bool fastTry = valid && k != 0u;
+            if constexpr (NS > 0) {
+                const unsigned long long fastMask = __ballot(fastTry);
+                if (fastMask != 0ull) {
+                    // the search's interface-0 test first, exactly as a B pass takes it (a try that dies there leaves (o, d) untouched)
+                    bool near0 = false;
+                    const bool pass0 = interface0_clear_fast<true>(load_surface<false>(kernarg_fast_surfaces(), 0), o, d, near0);
+                    const bool cand = fastTry && pass0 && !near0;
+                    unsure = fastTry && near0;
+                    unsigned long long tirMask, unsureMask;
+                    V3 ot = o, dt = d;
+                    const unsigned long long alive = trace_lens_fast_pred<NS, true>(kernarg_fast_surfaces(), ot, dt, __ballot(cand), tirMask, unsureMask);
+                    if (cand) {
+                        ok = mask_bit(alive, lane);
+                        tirTry = mask_bit(tirMask, lane) ? 1u : 0u;
+                        unsure |= mask_bit(unsureMask, lane);
+                        if (ok) { o = ot; d = dt; }
+                        else if (!unsure) { uint32_t ignored = 0; (void)trace_lens_fast_rolled(T, o, d, ignored); }   // the partial state of a failed try (only try 26's is ever handed out)
                     }
                 }
+            } else if (fastTry) ok = trace_lens_fast_rolled(T, o, d, tirTry, &unsure);
+            if (valid && (k == 0u || unsure)) {   // the reference's arithmetic: try 0, and a try too close to call (same draws)
+                o = o0; tirTry = 0;
+                if (k != 0u) d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+                ok = trace_lens_strict(T, o, d, tirTry);
             }
             // the next try of this lane, k + G, starts at draw 2 (k + G - 1): G - 1 pairs past where this try ended (2 k; try 0 drew nothing)
             for (uint32_t a = 0; a + 1u < kShortGroup; ++a) { (void)xor128(rng); (void)xor128(rng); }
@@ -187,7 +210,7 @@ __device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const Bokeh
     }
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
-    if (n <= kShortList) { listed_short_hybrid(T, B, lutLds, bokehLds, samples, n, out); return; }
+    if (n <= kShortList) { listed_short_hybrid<NS>(T, B, lutLds, bokehLds, samples, n, out); return; }
 
     // the double-ended array: pool entries 0 .. poolCnt-1, STRICT stack entries kListedEntries-1 downwards
     float4 *pool0 = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords + wave * kListedWaveWords);   // idx, o0x, o0y, packed
