@@ -11,7 +11,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libzoic_oracle.so")
+# ZOIC_ORACLE_LIB: another build of the SAME source (tests/test_oracle_assumptions.py: other compilers / optimisation levels /
+# the two variant hooks); never consulted by the product
+_LIB_PATH = os.environ.get("ZOIC_ORACLE_LIB") or os.path.join(_HERE, "libzoic_oracle.so")
 
 THINLENS, RAYTRACED, NONE = 0, 1, 2
 
@@ -22,6 +24,8 @@ ERR_NAMES = {0: "OK", 1: "LENS_PATH", 2: "LENS_COLUMNS", 3: "MULTI_APERTURE", 4:
 def build(force=False):
     """Compile the C restatement with gcc (strict IEEE flags live in oracle/Makefile)."""
     src = os.path.join(_HERE, "zoic_oracle.c")
+    if os.environ.get("ZOIC_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libzoic_oracle.so"])
     return _LIB_PATH

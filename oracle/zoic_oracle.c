@@ -949,9 +949,16 @@ void zo_create_ray(zo_camera *camera, const zo_input *input, zo_output *output, 
                 output->origin = kolb_origin_original;
                 float u = (float)((double)zo_xor128(rng) / 4294967296.0);   /* :1930 */
                 float v = (float)((double)zo_xor128(rng) / 4294967296.0);
+#ifdef ZO_VARIANT_SWAP_UV   /* tests/test_oracle_assumptions.py only: g++'s right-to-left evaluation of the two xor128() arguments */
+                { float t_ = u; u = v; v = t_; }
+#endif
                 sample_lens(camera, u, v, &lens);
                 lens.x *= maxScale; lens.y *= maxScale;
+#ifdef ZO_VARIANT_RETRY_X_ONLY   /* tests/test_oracle_assumptions.py only: what :1933 would be if it read like :1914 */
+                lens.x += translation;
+#else
                 lens.x += translation; lens.y += translation;           /* :1933 (both components) */
+#endif
                 lensx_rotated = lens.x * cos - lens.y * sin;
                 lensy_rotated = lens.x * sin + lens.y * cos;
                 lens.x = lensx_rotated; lens.y = lensy_rotated;

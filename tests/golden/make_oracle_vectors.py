@@ -30,4 +30,4 @@ for cfg in ("C1", "C1ov", "C2", "C3", "C4", "C5"):
     r = oc.create_rays(s, rng_states=st)
     out[cfg + "_samples"], out[cfg + "_states"], out[cfg + "_planes"], out[cfg + "_flags"] = s, st, r["planes"], r["flags"]
     print(cfg, "zero_w", float((r["weight"] == 0).mean()), "retried", float((r["flags"] & 1).mean()))
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"), **out)
+np.savez_compressed(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"), **out)

@@ -562,7 +562,9 @@ REFERENCE_PROBE_STATS = {"C2": (0.19, 0.24), "C3": (0.0007, 0.16), "C4": (0.0, 0
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_ray_statistics_match_the_reference_probe(gpu, cfg):
     """The one corroboration of the whole retry loop that does not go through the oracle: the fractions of zero-weight and
-    of retried rays the real reference produced for these cameras (+-2 % absolute: its sample jitter differs)."""
+    of retried rays the real reference produced for these cameras (figures quoted to two digits: +-0.5 % absolute).
+    tests/test_oracle_assumptions.py shows what these figures pin (the both-component translation of a retry, zoic.cpp:1933:
+    translated in x only, TESSAR's 19 % zero-weight would be 0) and what no statistic can (the order of a retry's two draws)."""
     from zoic_amd import PRECISION_FAST, PRECISION_STRICT
     cam = ZoicCamera(0)
     if CONFIGS[cfg]["bokeh"]:
@@ -575,7 +577,7 @@ def test_ray_statistics_match_the_reference_probe(gpu, cfg):
         cam.set_precision(mode)
         got = cam.create_rays(s)
         zero, retried = float((got["weight"] == 0).mean()), float((got["flags"] & 1).mean())
-        assert abs(zero - zero_ref) < 0.02 and abs(retried - retried_ref) < 0.02, (cfg, mode, zero, retried)
+        assert abs(zero - zero_ref) < 0.005 and abs(retried - retried_ref) < 0.005, (cfg, mode, zero, retried)
     cam.close()
 
 
