@@ -21,7 +21,10 @@
 //     C  64 rays of the STRICT stack : that try again, in the reference's arithmetic; the failures return to the pool
 // The pool and the STRICT stack share one double-ended LDS array of 192 entries per wave (B is taken first while the pool holds
 // 64, then C, then A: pool + stack never exceed 190).
-// Short lists: listed_short -- the tries of a ray side by side in the 16 lanes of a group (round 3), same rule per try.
+// Short lists (<= kShortList rays: every camera but the fisheye): their time is not work but ONE ray's chain of tries at one
+// wave per SIMD, so the tries of a ray run side by side in the G lanes of a group (round 3's listed_short), same rule per try.
+// G = 16 / 8 / 4 by the length of the list, so that all its waves are resident at once (4 per SIMD at 128 VGPRs = 4096 waves):
+// the chain that costs is try 0's STRICT trace, and a second generation of waves would pay it a second time.
 #pragma once
 #include "kolb_pool_body.hpp"
 
@@ -83,10 +86,12 @@ __device__ __forceinline__ ListedRay listed_one_ray(const KolbTable &T, const Bo
 // ray are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1); the first success in try order wins and
 // TIR bumps count for the tries before it only (try 26 hands out its state with weight 0 whether it got through or not,
 // zoic.cpp:1927 / 1951).
-template <int NS>
+__device__ __forceinline__ uint32_t short_group_for(uint32_t n) { return n <= 16384u ? 16u : (n <= 32768u ? 8u : 4u); }
+template <int NS, uint32_t kShortGroup>
 __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
                                                     const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out)
 {
+    constexpr uint32_t kShortRaysPerWave = 64u / kShortGroup;
     const uint32_t lane = threadIdx.x & 63u, j = lane % kShortGroup, g = lane / kShortGroup;
     const uint32_t wavesTotal = gridDim.x * kWavesPerBlock, waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t *list = ZOIC_KARG(redoList);
@@ -195,7 +200,8 @@ __device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const Bokeh
     if (n == 0u) return;
     // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times over
     const uint32_t redoChunk = n > (1u << 20) ? 256u : 64u;
-    const uint32_t totalChunks = n <= kShortList ? (n + kShortRaysPerWave - 1u) / kShortRaysPerWave : (n + redoChunk - 1u) / redoChunk;
+    const uint32_t shortGroup = short_group_for(n), shortRaysPerWave = 64u / shortGroup;
+    const uint32_t totalChunks = n <= kShortList ? (n + shortRaysPerWave - 1u) / shortRaysPerWave : (n + redoChunk - 1u) / redoChunk;
     if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed for it
     const uint32_t redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -210,7 +216,12 @@ __device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const Bokeh
     }
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
-    if (n <= kShortList) { listed_short_hybrid<NS>(T, B, lutLds, bokehLds, samples, n, out); return; }
+    if (n <= kShortList) {
+        if (shortGroup == 16u) listed_short_hybrid<NS, 16u>(T, B, lutLds, bokehLds, samples, n, out);
+        else if (shortGroup == 8u) listed_short_hybrid<NS, 8u>(T, B, lutLds, bokehLds, samples, n, out);
+        else listed_short_hybrid<NS, 4u>(T, B, lutLds, bokehLds, samples, n, out);
+        return;
+    }
 
     // the double-ended array: pool entries 0 .. poolCnt-1, STRICT stack entries kListedEntries-1 downwards
     float4 *pool0 = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords + wave * kListedWaveWords);   // idx, o0x, o0y, packed

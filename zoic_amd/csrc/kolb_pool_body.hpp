@@ -66,8 +66,8 @@ __device__ __forceinline__ V kernarg_field()
 //   GUARD (FAST only): every accept/reject decision of a try at a guarded interface (tables.hpp FastSurface::housingLo/Hi: in
 //       practice the stop) is checked against its guard band; a ray with a decision too close to call is dropped where it
 //       stands -- no record, no counter -- and its index goes to the work list `redoList`;
-//   LISTED (STRICT only) = the kernel that runs next on the stream and evaluates exactly the listed rays from scratch in
-//       the reference's arithmetic (per-ray retry streams make that the same ray).
+//   LISTED = kolb_listed_kernel (kolb_listed_body.hpp), next on the stream: evaluates exactly the listed rays from scratch, in the
+//       reference's arithmetic wherever a decision is too close to call (per-ray retry streams make that the same ray).
 // Together: every ray's try count, weight and flags are those of a STRICT evaluation unless FAST and STRICT disagree on a
 // decision OUTSIDE the guarded interfaces (sphere miss, TIR, a clip at a well-conditioned housing: residual flips <= ~1e-6 of
 // the rays, tests/test_parity_gpu.py); only the low-order bits of origin / direction of the FAST-evaluated rays differ.
@@ -232,122 +232,23 @@ __device__ __forceinline__ uint32_t mask_rank(unsigned long long m)   // exclusi
 }
 __device__ __forceinline__ bool mask_bit(unsigned long long m, uint32_t lane) { return ((m >> lane) & 1ull) != 0ull; }
 
-// listed_short: the STRICT evaluation of a SHORT work list (kShortList rays or fewer), G = 16 tries of a ray side by side.
-// The decision-safe launch ends with the STRICT kernel over the rays the FAST kernel could not decide; on all but the fisheye
-// that list is a few thousand rays and the kernel's time is not work but ONE ray's chain of sequential tries (up to 27 passes
-// of ~5 us at one wave per SIMD: 80 us of a 570 us TESSAR frame, 80 us on top of a 110 us 1 M-ray bucket).  The tries of a ray
-// are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1), so the G lanes of group g of a wave evaluate
-// tries G r .. G r + G - 1 of ray g in round r (two rounds at most; G = 4 / 8 / 16 measured: 180 / 155 / 144 us for a 1 M-ray
-// decision-safe TESSAR bucket, 191 with the pool path) -- the reference's own loop body (zoic.cpp:1870-1947: lens sample, direction, branchy
-// trace), no pool, no shortcuts -- and the first success in try order wins; TIR bumps count for the tries before it only.
-// Same device functions, same per-ray streams: the same bits as the pool path.
+// work lists of kShortList rays or fewer are evaluated tries-in-parallel by the listed kernel (kolb_listed_body.hpp)
 constexpr uint32_t kShortList = 1u << 17;
-#ifndef ZOIC_SHORT_GROUP
-#define ZOIC_SHORT_GROUP 16   // lanes (= tries evaluated side by side) per listed ray: 4 / 8 / 16
-#endif
-constexpr uint32_t kShortGroup = ZOIC_SHORT_GROUP, kShortRaysPerWave = 64u / kShortGroup;
-__device__ __forceinline__ void listed_short(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
-                                             const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out)
-{
-    const uint32_t lane = threadIdx.x & 63u, j = lane % kShortGroup, g = lane / kShortGroup;
-    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock, waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const uint32_t *list = ZOIC_KARG(redoList);
-    const uint4 *states = ZOIC_KARG(rngStates);
-    const uint64_t rayBase = ZOIC_KARG(rayBase);
-    uint32_t succ = 0, vign = 0, tir = 0;   // per lane; reduced at the end
-    for (uint32_t first = waveId * kShortRaysPerWave; first < n; first += wavesTotal * kShortRaysPerWave) {
-        const uint32_t li = first + g;
-        const bool have = li < n;
-        const uint32_t idx = list[have ? li : n - 1u];
-        const float4 s = samples[idx];
-        const RaySetup rs = setup_ray<true>(T, lutLds, s.x, s.y);
-        const V3 o0{rs.o0x, rs.o0y, T.originShift};
-        Rng rng;
-        if (states) { const uint4 q = states[idx]; rng = Rng{q.x, q.y, q.z, q.w}; }
-        else rng = rng_for_ray(T.seed, rayBase + idx);
-        for (uint32_t a = 1; a < j; ++a) { (void)xor128(rng); (void)xor128(rng); }   // lane j >= 1 starts at draw 2 (j - 1)
-        bool done = !have;
-        for (uint32_t round = 0; round * kShortGroup <= static_cast<uint32_t>(kMaxTries) + 1u; ++round) {
-            const uint32_t k = kShortGroup * round + j;                      // this lane's try: 0 = the sample's own lens point, k = tries
-            const bool valid = !done && k <= static_cast<uint32_t>(kMaxTries) + 1u;
-            V3 o = o0, d{0.0f, 0.0f, 1.0f};
-            uint32_t tirTry = 0;
-            bool ok = false;
-            if (valid) {
-                if (k == 0u) {
-                    V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
-                    if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
-                    else {                                                    // zoic.cpp:1913-1924: x-only translation
-                        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
-                        lens.x += rs.translation;
-                        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
-                        d = V3{rx - o.x, ry - o.y, T.dirZ};
-                    }
-                } else {
-                    const float u = rng_unit(xor128(rng));                    // zoic.cpp:1930
-                    const float v = rng_unit(xor128(rng));
-                    d = retry_direction(T, lens_sample<true>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-                }
-                ok = trace_lens_strict(T, o, d, tirTry);
-            }
-            // the next try of this lane, k + G, starts at draw 2 (k + G - 1): G - 1 pairs past where this try ended (2 k; try 0 drew nothing)
-            for (uint32_t a = 0; a + 1u < kShortGroup; ++a) { (void)xor128(rng); (void)xor128(rng); }
-            // the group's decision, in try order
-            const unsigned long long okAll = __ballot(valid && ok);
-            const uint32_t okGroup = static_cast<uint32_t>(okAll >> (kShortGroup * g)) & ((1u << kShortGroup) - 1u);
-            const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : kShortGroup;   // lowest try that got through
-            if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
-            const bool last = k == static_cast<uint32_t>(kMaxTries) + 1u;      // try 26 failed as well: weight 0, ITS partial state
-            if (valid && (j == winner || (winner == kShortGroup && last))) {
-                // try 26 is still traced by the loop condition (zoic.cpp:1927) and hands out its state, but tries > 25 is weight 0
-                // whether it got through or not (zoic.cpp:1951-1957)
-                const bool okRay = j == winner && !last;
-                float w = okRay ? 1.0f : 0.0f;
-                if (T.exposureOn) w *= T.exposureMul;                          // zoic.cpp:1981-1987
-                store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
-                                 (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6));
-                if (okRay) ++succ; else ++vign;
-            }
-            done = done || winner != kShortGroup || kShortGroup * (round + 1u) > static_cast<uint32_t>(kMaxTries) + 1u;
-            if (__ballot(!done) == 0ull) break;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) { succ += __shfl_xor(succ, off, 64); vign += __shfl_xor(vign, off, 64); tir += __shfl_xor(tir, off, 64); }
-    DeviceCounters *counters = counter_set(ZOIC_KARG(counters));
-    if (counters && lane == 0) {
-        if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
-        if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
-        if (tir) atomicAdd(&counters->tir, static_cast<unsigned long long>(tir));
-    }
-}
-
 // IMAGE: the bokeh image is on AND its cell records are in LDS (tables.hpp; images up to 2048 rows x 4096 columns): every
 // lens sample is one ds_read_b128 + one global_load_dwordx4.  IMAGE = false covers the concentric-disk sampler and images
 // without records (16-ary pyramid / reference search through lens_sample's run-time branch).
-template <bool STRICT, int NS, bool GUARD, bool LISTED, bool DEAD, bool IMAGE>
+template <bool STRICT, int NS, bool GUARD, bool DEAD, bool IMAGE>
 __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
                                                uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching)
 {
-    static_assert(!(GUARD && STRICT) && !(LISTED && !STRICT), "GUARD is a FAST mode, LISTED the STRICT kernel behind it");
+    static_assert(!(GUARD && STRICT), "GUARD is a FAST mode");
     constexpr bool DEFER = GUARD || DEAD;   // rays may leave the pass loop unfinished: TIR bumps are tallied per ray
     constexpr bool PROBE = IMAGE && (!STRICT || ZOIC_POOL_PROBE_STRICT != 0);   // the next batch's first lens sample is requested a pass ahead
     constexpr uint32_t kOut = static_cast<uint32_t>(kMaxTries) + 1u;   // tries of a ray that ran out (zoic.cpp:1927: tries <= 25)
-    uint32_t redoChunk = 0, redoChunksPerPart = 0;
-    if constexpr (LISTED) {   // the work list's length is only known on the device
-        n = *ZOIC_KARG(redoCount);   // <= samples of the launch, which is what the list was sized for
-        if (n == 0u) return;
-        // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times over
-        redoChunk = n > (1u << 20) ? 256u : 64u;
-        const uint32_t totalChunks = n <= kShortList ? (n + kShortRaysPerWave - 1u) / kShortRaysPerWave : (n + redoChunk - 1u) / redoChunk;   // short lists: listed_short
-        if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed for it
-        redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
-    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if constexpr (!LISTED) {   // the other cursor block of this launch slot, for the launch after this one (kernels.hpp)
-        if (blockIdx.x == 0) {
-            unsigned int *next = ZOIC_KARG(clearCursor);
-            for (uint32_t i = threadIdx.x; i < kCursorBlockWords; i += kRefillBlock) next[i] = 0u;
-        }
+    if (blockIdx.x == 0) {   // the other cursor block of this launch slot, for the launch after this one (kernels.hpp)
+        unsigned int *next = ZOIC_KARG(clearCursor);
+        for (uint32_t i = threadIdx.x; i < kCursorBlockWords; i += kRefillBlock) next[i] = 0u;
     }
     // LDS, once per workgroup: the 32 exit-pupil LUT pairs (maxScale, centroid.x) -- one ds_read_b128 fetches the two entries
     // a sample interpolates -- then the bokeh row cell records (tables.hpp)
@@ -362,9 +263,6 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     }
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
-    if constexpr (LISTED) {
-        if (n <= kShortList) { listed_short(T, B, lutLds, bokehLds, samples, n, out); return; }
-    }
     float4 *pool0 = reinterpret_cast<float4 *>(zoicDynLds + kLutLdsWords + ldsWords + wave * kPoolWaveWords);   // idx, o0x, o0y, packed
     uint4 *pool2 = reinterpret_cast<uint4 *>(pool0 + kPoolEntries);                                             // the ray's retry stream
 #if ZOIC_POOL_SLIM
@@ -388,25 +286,23 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     // cell record of its FIRST lens sample is already requested (zoic.cpp:1870) -- and b2, requested one pass before that.
     uint32_t next = 0, end = 0, part = blockIdx.x % kCursorParts, partsTried = 0;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    uint32_t idx1 = 0, idx2 = 0, base1 = 0, base2 = 0, cnt1 = 0, cnt2 = 0;   // idx: LISTED only
+    uint32_t base1 = 0, base2 = 0, cnt1 = 0, cnt2 = 0;
     bool have1 = false, have2 = false;
     CellProbe probe{make_uint4(0u, 0u, 0u, 0u), 0, 0u};
     const auto request_batch = [&]() {   // -> b2
         have2 = false;
         if (next >= end) {   // claim the next chunk: one atomic per chunkRays samples per wave
-            const uint32_t cr = LISTED ? redoChunk : ZOIC_KARG(chunkRays), cpp = LISTED ? redoChunksPerPart : ZOIC_KARG(chunksPerPart);
-            if (!claim_chunk(ZOIC_KARG(workCursor), lane, part, partsTried, cr, cpp, n, next, end)) return;
+            if (!claim_chunk(ZOIC_KARG(workCursor), lane, part, partsTried, ZOIC_KARG(chunkRays), ZOIC_KARG(chunksPerPart), n, next, end)) return;
         }
         base2 = next;
         cnt2 = (end - next < 64u) ? end - next : 64u;
         const uint32_t wi = (lane < cnt2) ? next + lane : next;
-        if constexpr (LISTED) { idx2 = ZOIC_KARG(redoList)[wi]; s2 = samples[idx2]; }
-        else s2 = samples[wi];
+        s2 = samples[wi];
         next += cnt2;
         have2 = true;
     };
     const auto advance_batches = [&]() {   // b1 <- b2 (+ its probe), b2 <- the next request
-        s1 = s2; idx1 = idx2; base1 = base2; cnt1 = cnt2; have1 = have2;
+        s1 = s2; base1 = base2; cnt1 = cnt2; have1 = have2;
         if constexpr (PROBE) { if (have1) probe = bokeh_cells_issue(B, bokehLds, T.bokehH, s1.z, s1.w); }
         if (have1) request_batch();
     };
@@ -458,7 +354,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         if (!fromPool) {
             // phase A: set 64 fresh rays up and run the search's FIRST step for all of them (zoic.cpp:1853-1925)
             active = lane < cnt1;
-            idx = LISTED ? idx1 : base1 + lane;
+            idx = base1 + lane;
                 const RaySetup rs = setup_ray<STRICT>(T, lutLds, s1.x, s1.y);
             o0x = rs.o0x; o0y = rs.o0y; maxScale = rs.maxScale; translation = rs.translation; sn = rs.sn; cs = rs.cs;
             lutMiss = rs.flags; dead = rs.dead;
@@ -664,10 +560,6 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             succ += static_cast<uint32_t>(__popcll(__ballot(finished))) - nv;
             ZOIC_PS_ADD(7, __popcll(__ballot(finished)))
 #ifdef ZOIC_PS_LIST
-            if constexpr (LISTED) {
-                ZOIC_PS_LISTADD(2, __popcll(__ballot(finished)))
-                for (uint32_t b = 0; b < 5u; ++b) ZOIC_PS_LISTADD(3, static_cast<unsigned long long>(__popcll(__ballot(finished && ((tries >> b) & 1u)))) << b)
-            }
             if constexpr (GUARD) {
                 ZOIC_PS_LISTADD(0, __popcll(__ballot(dropU)))
                 for (uint32_t b = 0; b < 5u; ++b) ZOIC_PS_LISTADD(1, static_cast<unsigned long long>(__popcll(__ballot(dropU && ((tries >> b) & 1u)))) << b)
@@ -781,15 +673,15 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         uint64_t rayBase, uint32_t n, RayRecord *__restrict__ out, DeviceCounters *counters, unsigned int *__restrict__ workCursor,        \
         uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList,             \
         unsigned int *__restrict__ redoCount, unsigned int *__restrict__ clearCursor
-#define ZOIC_POOL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_, LISTED_)                                                               \
+#define ZOIC_POOL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_)                                                                        \
     template <int NS, bool DEAD, bool IMAGE>                                                                                 \
     __global__ __launch_bounds__(kRefillBlock) ATTR_ void NAME_(ZOIC_POOL_PARAMS)                                             \
     {                                                                                                                        \
-        kolb_pool_body<STRICT_, NS, GUARD_, LISTED_, DEAD, IMAGE>(T, B, samples, n, out, ldsWords, minSearching);             \
+        kolb_pool_body<STRICT_, NS, GUARD_, DEAD, IMAGE>(T, B, samples, n, out, ldsWords, minSearching);                      \
     }
-ZOIC_POOL_KERNEL(kolb_pool_strict_kernel, ZOIC_POOL_ATTR_STRICT, true, false, false)          // STRICT, whole batch
-ZOIC_POOL_KERNEL(kolb_pool_fast_kernel, ZOIC_POOL_ATTR_FAST, false, false, false)             // FAST unchecked
-ZOIC_POOL_KERNEL(kolb_pool_guard_kernel, ZOIC_POOL_ATTR_FAST, false, true, false)             // FAST decision-safe
+ZOIC_POOL_KERNEL(kolb_pool_strict_kernel, ZOIC_POOL_ATTR_STRICT, true, false)          // STRICT, whole batch
+ZOIC_POOL_KERNEL(kolb_pool_fast_kernel, ZOIC_POOL_ATTR_FAST, false, false)             // FAST unchecked
+ZOIC_POOL_KERNEL(kolb_pool_guard_kernel, ZOIC_POOL_ATTR_FAST, false, true)             // FAST decision-safe: lists what it cannot decide for kolb_listed_kernel
 #undef ZOIC_POOL_KERNEL
 #undef ZOIC_POOL_PARAMS
 
