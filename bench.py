@@ -45,7 +45,7 @@ CPU_SLAB_RAYS = 16_588_800       # the fixed slab (= config 2's ful
 
 NOTES = {
     "roofline": "achieved = 44 B/ray (SURVEY 8d: 16 B sample + 28 B origin/dir/weight) x rays / kernel_ms; kernel_ms = the launch (main kernel + "
-                "STRICT kernel over its work list) by HIP events on the launch stream; frac48 = the same with the 32 B record the kernels "
+                "the listed kernel over its work list) by HIP events on the launch stream; frac48 = the same with the 32 B record the kernels "
                 "really write; flop_frac = FLOP/ray counted by the oracle (profiles/flop_model_r04.json: 106 x interface visits + 130 x "
                 "tries) x rays/s over 157 TFLOP/s; traffic, lane_instr, lane_util = the committed rocprofv3 PMC run of this (config, "
                 "mode), profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE) -- null when the kernel sources have changed since "
@@ -254,7 +254,7 @@ def roofline_block(cfg_name, precision, n, kernel_ms, thin):
     roof = {"bound": "hbm" if thin else "valu", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(ent["hbm_bytes_per_launch"]) if ent else None, "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": ALGO_BYTES_PER_RAY,
             "frac48": round(RECORD_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "kernel": "thin_rays_kernel" if thin else {"fast": "kolb_pool_guard_kernel + kolb_pool_strict_listed_kernel", "unchecked": "kolb_pool_fast_kernel",
+            "kernel": "thin_rays_kernel" if thin else {"fast": "kolb_pool_guard_kernel + kolb_listed_kernel", "unchecked": "kolb_pool_fast_kernel",
                                                         "strict": "kolb_pool_strict_kernel"}[precision]}
     fl = None if thin else flop_per_ray(cfg_name)
     if fl:

@@ -236,6 +236,29 @@ __device__ __forceinline__ bool trace_lens_fast_rolled(const KolbTable &T, V3 &o
     return ok;
 }
 
+// The same from interface `first` on (the listed kernel continues behind the stop, kolb_listed_body.hpp): d is normalised like a
+// fresh direction; the table words come through the kernarg pointer (a run-time index into the by-value KolbTable makes the
+// compiler copy its arrays to scratch: 2.9 KB per lane and a listed kernel six times slower, round 4).
+__device__ __forceinline__ bool trace_lens_fast_rolled_from(FastSurfaceTable surf, int n, int first, V3 &o, V3 &d, uint32_t &tirCount, bool *unsure)
+{
+    const float inv = frsq_fast(fast_norm2(d));
+    V3 u{d.x * inv, d.y * inv, d.z * inv};
+    float oAxis2 = fast_axis2(o);
+    bool ok = true, refracted = false;
+    for (int i = first; i < n;) {
+        const int iu = __builtin_amdgcn_readfirstlane(i);
+        const FastSurface S = load_surface<false>(surf, iu);
+        bool near = false;
+        const int r = fast_interface(S, o, oAxis2, u, &near);
+        *unsure |= near;
+        if (r != 0) { if (r == 2) ++tirCount; ok = false; break; }
+        refracted = true;
+        ++i;
+    }
+    if (refracted) d = u;
+    return ok;
+}
+
 // Predicated, fully unrolled trace for a lens with exactly NS interfaces: NO divergent control flow.  Every lane
 // evaluates every interface; a lane that is clipped or totally reflected only clears its bit in the `alive` mask.  The
 // masks are plain 64-bit scalars (one v_cmp into an SGPR pair per decision, s_and / s_andn2 / s_or to combine them): no

@@ -94,13 +94,16 @@ __device__ __forceinline__ bool interface0_clear_strict_lean(const KolbTable &T,
     return !((d2 > S.radius2) | (h2 > S.housing2));
 }
 
-template <int NS>
-__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool alive0, bool &outOfRange)
+// RANGE (the listed kernel, kolb_listed_body.hpp): only interfaces first ... last (wave-uniform run-time bounds) are traced
+template <int NS, bool RANGE = false>
+__device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool alive0, bool &outOfRange,
+                                                       int first = 0, int last = NS - 1)
 {
     static_assert(NS > 0, "predicated trace needs a compile-time interface count");
     bool alive = alive0, tirSeen = false, anyAlive = true, oor = false;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
+        if constexpr (RANGE) { if (i < first || i > last) continue; }
         if (i >= 2 && (i & 1) == 0) anyAlive = __ballot(alive) != 0ull;
         if (!anyAlive) continue;
         const Surface &S = T.surf[i];

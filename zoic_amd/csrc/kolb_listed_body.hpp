@@ -8,9 +8,16 @@
 // than any other (1.85 %).  The rule here -- the same for every listed ray whatever the length of the list, so that a ray's
 // bits do not depend on how a frame is cut into launches (a sharded frame equals the one-GPU frame):
 //     set-up            : the reference's arithmetic (setup_ray<true>)
-//     try 0             : the reference's arithmetic (83 % of the listed rays were listed AT their first try)
+//     try 0             : a STRICT try (83 % of the listed rays were listed AT their first try)
 //     try k >= 1        : FAST arithmetic with its guard bands on the STRICT set-up constants; a try with a decision inside a
-//                         guard band is evaluated again in the reference's arithmetic (same draws) and THAT result stands.
+//                         guard band is evaluated again as a STRICT try (same draws) and THAT result stands.
+//     a STRICT try      : lens sample and direction in the reference's arithmetic, the trace in the reference's arithmetic UP TO AND
+//                         INCLUDING THE STOP (listed_strict_try).  The stop is where the reference's own rounding decides (a sphere
+//                         of |R| ~ 1e4 cm: the hit point is good to ~ulp(|R|)) and why the ray was listed; behind it the trace goes on
+//                         in FAST arithmetic with its guard bands from the STRICT state at the stop, and only if one of THOSE clips is
+//                         too close to call (bands of a few ulps: ~1e-5 of the tries) the rest is traced in the reference's
+//                         arithmetic from the stop on instead.  Half of a 12-interface STRICT trace (160 instructions per
+//                         interface against 29) is saved.
 // Every accept / reject decision is therefore either a FAST decision outside every guard band or a STRICT one -- what
 // "decision-safe" means (include/zoic_amd.h, ZOIC_PRECISION_FAST).
 //
@@ -42,6 +49,68 @@ __device__ __forceinline__ V3 listed_retry_direction_strict(const KolbTable &T, 
     return retry_direction(T, lens_sample<true>(T, B, bokehLds, u, v), o0x, o0y, maxScale, translation, sn, cs);
 }
 
+// A STRICT try's trace (see the rule above), branchy: leaves (o, d) as the arithmetic that decided leaves them.
+__device__ __forceinline__ bool listed_strict_try(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+{
+    const int n = T.lensCount, stop = T.apertureElement;
+    if (!trace_lens_strict_range(T, o, d, tirCount, 0, stop)) return false;
+    if (stop + 1 >= n) return true;
+    const V3 os = o, ds = d;
+    uint32_t tirFast = 0;
+    bool unsure = false;
+    const bool ok = trace_lens_fast_rolled_from(kernarg_fast_surfaces(), n, stop + 1, o, d, tirFast, &unsure);
+    if (!unsure) { tirCount += tirFast; return ok; }
+    o = os; d = ds;
+    return trace_lens_strict_range(T, o, d, tirCount, stop + 1, n - 1);
+}
+
+// the same, predicated and unrolled for NS interfaces (alive lanes bit-identical to listed_strict_try; rays that FINISH failed
+// get their partial state from it).  The FAST tail has no early-out bookkeeping of its own: half a trace.
+template <int NS>
+__device__ __forceinline__ bool listed_strict_try_pred(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, bool cand, bool &outOfRange)
+{
+    const int stop = T.apertureElement;
+    bool alive = trace_lens_strict_pred<NS, true>(T, o, d, tirCount, cand, outOfRange, 0, stop);
+    if (stop + 1 >= NS) return alive;
+    const unsigned long long aliveMask = __ballot(alive);
+    if (aliveMask == 0ull) return false;
+    const V3 os = o, ds = d;
+    // FAST tail from the STRICT state at the stop (fast_optics.hpp: the arithmetic of trace_lens_fast_pred / _rolled)
+    const FastSurfaceTable surf = kernarg_fast_surfaces();
+    const float inv = frsq_fast(fast_norm2(d));
+    V3 u{d.x * inv, d.y * inv, d.z * inv};
+    float oAxis2 = fast_axis2(o);
+    unsigned long long al = aliveMask, tirSeen = 0ull, unsure = 0ull, nanRays = 0ull;
+    bool firstTail = true;
+#pragma unroll
+    for (int i = 1; i < NS; ++i) {
+        if (i <= stop) continue;
+        const FastSurface S = load_surface<true>(surf, i);
+        const FastHit h = fast_hit(S, o, oAxis2, u);
+        if (firstTail) { nanRays = __ballot(is_nan_ray(h)); firstTail = false; }   // a NaN ray "passes" every comparison of the reference
+        const unsigned long long clipped = ~__ballot(h.h2 <= S.housingLo);
+        unsure |= al & clipped & __ballot(h.h2 <= S.housingHi);
+        o = h.hit;
+        oAxis2 = h.h2;
+        const unsigned long long tirHere = __ballot(fast_refract(S, h, u) < 0.0f);
+        al &= ~clipped;
+        tirSeen |= al & tirHere;
+        al &= ~tirHere;
+    }
+    d = u;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool ok = mask_bit(al | (aliveMask & nanRays), lane);
+    if (alive && !mask_bit(unsure, lane)) tirCount += mask_bit(tirSeen, lane) ? 1u : 0u;
+    if (__builtin_expect(unsure != 0ull, 0)) {   // a clip behind the stop too close to call: the rest in the reference's arithmetic
+        const bool redo = alive && mask_bit(unsure, lane);
+        V3 o2 = os, d2 = ds;
+        bool oor2 = false;
+        const bool ok2 = trace_lens_strict_pred<NS, true>(T, o2, d2, tirCount, redo, oor2, stop + 1, NS - 1);
+        if (redo) { o = o2; d = d2; ok = ok2; outOfRange |= oor2; }
+    }
+    return ok;
+}
+
 // The rule above for ONE ray, sequentially (the per-sample mailbox kernel; the batch kernels below evaluate the same tries with
 // the same device functions, 64 rays or 16 tries at a time).  rng: the ray's retry stream at its first draw.
 struct ListedRay { V3 o, d; float w; uint32_t tries, lutMiss, tir; };
@@ -60,7 +129,7 @@ __device__ __forceinline__ ListedRay listed_one_ray(const KolbTable &T, const Bo
         r.d = V3{rx - o0.x, ry - o0.y, T.dirZ};
     }
     r.o = o0;
-    bool ok = trace_lens_strict(T, r.o, r.d, r.tir);
+    bool ok = listed_strict_try(T, r.o, r.d, r.tir);
     while (!ok && r.tries <= static_cast<uint32_t>(kMaxTries)) {      // zoic.cpp:1927
         const float u = rng_unit(xor128(rng));                        // zoic.cpp:1930
         const float v = rng_unit(xor128(rng));
@@ -73,7 +142,7 @@ __device__ __forceinline__ ListedRay listed_one_ray(const KolbTable &T, const Bo
         if (unsure) {
             r.o = o0; tirTry = 0;
             r.d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-            ok = trace_lens_strict(T, r.o, r.d, tirTry);
+            ok = listed_strict_try(T, r.o, r.d, tirTry);
         }
         r.tir += tirTry;
     }
@@ -160,7 +229,7 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
             if (valid && (k == 0u || unsure)) {   // the reference's arithmetic: try 0, and a try too close to call (same draws)
                 o = o0; tirTry = 0;
                 if (k != 0u) d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-                ok = trace_lens_strict(T, o, d, tirTry);
+                ok = listed_strict_try(T, o, d, tirTry);
             }
             // the next try of this lane, k + G, starts at draw 2 (k + G - 1): G - 1 pairs past where this try ended (2 k; try 0 drew nothing)
             for (uint32_t a = 0; a + 1u < kShortGroup; ++a) { (void)xor128(rng); (void)xor128(rng); }
@@ -360,11 +429,11 @@ __device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const Bokeh
             if (strictPass) {
                 if constexpr (NS > 0) {
                     bool oor = false;
-                    ok = trace_lens_strict_pred<NS>(T, o, d, tirTry, cand, oor);
+                    ok = listed_strict_try_pred<NS>(T, o, d, tirTry, cand, oor);
                     if (__builtin_expect(__ballot(cand && oor) != 0ull, 0)) {   // never seen: a root left the lean sequences' verified range
-                        if (cand && oor) { o = oStart; d = dStart; tirTry = 0; ok = trace_lens_strict(T, o, d, tirTry); }
+                        if (cand && oor) { o = oStart; d = dStart; tirTry = 0; ok = listed_strict_try(T, o, d, tirTry); }
                     }
-                } else if (cand) ok = trace_lens_strict(T, o, d, tirTry);
+                } else if (cand) ok = listed_strict_try(T, o, d, tirTry);
             } else {
                 if constexpr (NS > 0) {
                     unsigned long long tirMask, unsureMask;
@@ -385,7 +454,7 @@ __device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const Bokeh
                 if (cand && !ok && tries > static_cast<uint32_t>(kMaxTries) && !unsure) {
                     uint32_t ignored = 0;
                     o = oStart; d = dStart;
-                    if (strictPass) (void)trace_lens_strict(T, o, d, ignored);
+                    if (strictPass) (void)listed_strict_try(T, o, d, ignored);
                     else (void)trace_lens_fast_rolled(T, o, d, ignored);
                 }
             }

@@ -128,10 +128,11 @@ ZOIC_HD V2 concentric_disk(float ox, float oy)
 // ---- traceThroughLensElements, zoic.cpp:1099-1158 (== ...ForApertureSize, zoic.cpp:1309-1350) ------
 // o/d are updated in place exactly as the reference leaves them on every exit path (the caller relies on
 // the partial state when a ray exhausts its tries, zoic.cpp:1951-1961).
-ZOIC_HD bool trace_lens_strict(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+// (first, last: the interfaces to trace, inclusive -- the whole lens for the reference's loop; the listed kernel of the
+// decision-safe FAST mode traces up to the stop and from the stop on, kolb_listed_body.hpp)
+ZOIC_HD bool trace_lens_strict_range(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount, int first, int last)
 {
-    const int n = T.lensCount;
-    for (int ii = 0; ii < n; ++ii) {
+    for (int ii = first; ii <= last; ++ii) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // all lanes still looping are at the same surface: keep the index (and the table fetch) scalar
         const int i = __builtin_amdgcn_readfirstlane(ii);
@@ -167,6 +168,10 @@ ZOIC_HD bool trace_lens_strict(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCo
         d = V3{u.x * S.eta + N.x * k, u.y * S.eta + N.y * k, u.z * S.eta + N.z * k};
     }
     return true;
+}
+ZOIC_HD bool trace_lens_strict(const KolbTable &T, V3 &o, V3 &d, uint32_t &tirCount)
+{
+    return trace_lens_strict_range(T, o, d, tirCount, 0, T.lensCount - 1);
 }
 
 // The interface-0 half of trace_lens_strict, operation for operation: does the ray hit the rear sphere and clear its
