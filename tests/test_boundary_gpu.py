@@ -413,3 +413,33 @@ def test_current_device_is_left_alone(gpu):
     if torch.cuda.device_count() > 1:
         with pytest.raises(ValueError):
             cam.create_rays(torch.zeros((4, 4), device="cuda:1"))
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_per_sample_call_equals_the_batch_ray_of_the_same_stream_in_both_modes(gpu, cfg):
+    """One kernel family, one arithmetic per mode: the FIRST call of a fresh tid t draws its retries from the stream keyed by
+    (0xA7100000 | t) << 32 (capi.cpp tid_state), which is the batch path's stream of ray index (0xA7100000 | t) << 32 -- so that
+    call and a one-ray batch launch at that ray_index_base must produce the same ray, bit for bit, in STRICT *and* in FAST
+    (round 4: the FAST arithmetic is written with explicit FMAs, so the branchy trace of the per-sample kernel, the unrolled
+    trace of the batch kernels and the listed kernel's rule for rays too close to call all round alike)."""
+    from zoic_amd import PRECISION_FAST
+    c = CONFIGS[cfg]
+    s, _ = _slab(cfg, 4096, 0.37)
+    for mode in (PRECISION_STRICT, PRECISION_FAST):
+        cam = ZoicCamera(0)
+        if c["bokeh"]:
+            cam.set_bokeh_image(hexagon_bokeh())
+        cam.update(**camera_params(cfg))
+        cam.set_precision(mode)
+        first = cam.create_rays(s)
+        retried = np.nonzero(first["tries"] > 0)[0][:40]              # rays that draw from their stream ...
+        plain = np.nonzero(first["tries"] == 0)[0][:20]               # ... and some that do not
+        for t, k in enumerate(list(retried) + list(plain), start=1):
+            row = [float(v) for v in s[k]]
+            one = cam.create_ray(*row, tid=t)                          # the tid's first call: its stream is at its seed
+            got = cam.create_rays(s[k:k + 1], ray_index_base=(0xA7100000 | t) << 32)
+            want = np.array([got["planes"][i, 0] for i in range(6)], np.float32)
+            have = np.array([one.origin.x, one.origin.y, one.origin.z, one.dir.x, one.dir.y, one.dir.z], np.float32)
+            assert np.array_equal(bits(have), bits(want)), (cfg, mode, t, have, want)
+            assert np.float32(one.weight[0]) == got["planes"][6, 0]
+        cam.close()

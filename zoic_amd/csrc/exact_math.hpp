@@ -45,6 +45,24 @@ __device__ __forceinline__ float rcp_rn(float x)
     return 1.0f / x;
 }
 
+// The reference re-normalises vectors that are unit already (the surface normal a second time inside Snell, zoic.cpp:1010; the
+// refracted direction at the next interface, zoic.cpp:974): s = |a|^2 is then 1 to a few ulps, and for such s BOTH roundings of
+// t = 1 / sqrt(s) -- sqrtss, then divss -- are exact integer functions of the bits of s.  With i = bits(s) - bits(1.0f):
+//     bits(sqrt_rn(s))           = (bits(s) + 0x3f800000) >> 1                 (= 1.0f's bits + floor(i / 2): a tie rounds DOWN,
+//                                                                                the true root lies below 1 + e/2 by e^2/8)
+//     bits(rcp_rn(sqrt_rn(s)))   = 0x3f800000 - max(i & ~1, i >> 2)            (arithmetic shift)
+// exact for |i| <= 2048 (|s - 1| < 1.2e-4); tests/test_exact_math.py checks both against IEEE sqrt and divide on every one of
+// those 4097 values (and shows the second formula failing from i = 2898 on).  Seven integer instructions instead of
+// v_rsq + v_rcp + six FMA-class ones; outside the range the caller takes the lean sequences.
+constexpr int kUnitRange = 2048;
+__device__ __forceinline__ float rcp_sqrt_rn_near_one(float s, bool &inRange)
+{
+    const int i = __builtin_bit_cast(int, s) - 0x3f800000;
+    inRange = static_cast<uint32_t>(i + kUnitRange) <= static_cast<uint32_t>(2 * kUnitRange);
+    const int a = i & ~1, b = i >> 2;
+    return __builtin_bit_cast(float, 0x3f800000 - (a > b ? a : b));
+}
+
 // sqrt(|1 - cs2|) in f64 for a FLOAT cs2 (calculateTransmissionVector, zoic.cpp:1023: `std::sqrt(std::abs(1.0 - cs2))`):
 // the operand is a function of one float, so the whole domain is 2^32 values and tools/ubench/exact_math_check.hip compares
 // this sequence with the correctly rounded f64 square root on every one of them.  It is hipcc's own Newton scheme on

@@ -76,6 +76,14 @@ __device__ __forceinline__ V3 normalize3_lean(V3 a, bool &inRange)
     return V3{a.x * t, a.y * t, a.z * t};
 }
 
+// the same for a vector that is unit to rounding already (exact_math.hpp rcp_sqrt_rn_near_one): the same bits, no root at all
+__device__ __forceinline__ V3 normalize3_unit(V3 a, bool &inRange)
+{
+    const float s = a.x * a.x + a.y * a.y + a.z * a.z;
+    const float t = rcp_sqrt_rn_near_one(s, inRange);
+    return V3{a.x * t, a.y * t, a.z * t};
+}
+
 // interface0_clear_strict (optics.hpp) with the lean roots; `inRange` false: the caller repeats the test with the guarded ones
 __device__ __forceinline__ bool interface0_clear_strict_lean(const KolbTable &T, V3 o, V3 d, bool &inRange)
 {
@@ -108,7 +116,9 @@ __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o
         if (!anyAlive) continue;
         const Surface &S = T.surf[i];
         bool r0, r1, r2, r3;
-        V3 u = normalize3_lean(d, r0);
+        // behind the first interface d is Snell's output: unit to rounding (a lane where it is not -- never seen -- sets oor and the
+        // caller repeats the try through the guarded branchy trace)
+        V3 u = (i == 0) ? normalize3_lean(d, r0) : normalize3_unit(d, r0);
         V3 L{0.0f - o.x, 0.0f - o.y, S.center - o.z};
         float tca = dot3(L, u);
         float d2 = dot3(L, L) - (tca * tca);
@@ -122,7 +132,7 @@ __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o
         V3 nrm = normalize3_lean(V3{0.0f - hit.x, 0.0f - hit.y, S.center - hit.z}, r2);
         nrm = V3{nrm.x * S.sign, nrm.y * S.sign, nrm.z * S.sign};
         o = hit;
-        V3 N = normalize3_lean(nrm, r3);
+        V3 N = normalize3_unit(nrm, r3);      // zoic.cpp:1010: the normal, normalised a second time
         oor |= alive & !(r0 & r1 & r2 & r3);   // a lane still alive HERE consumed these roots
         float c1 = -dot3(u, N);
         float cs2 = static_cast<float>(static_cast<double>(S.eta * S.eta) * (1.0 - static_cast<double>(c1 * c1)));

@@ -16,8 +16,10 @@
 //   * the kernel retires by itself after 1 ms without a call and after 50 ms in any case (a resident kernel would stall the
 //     application's hipDeviceSynchronize / hipFree for ever); the next call finds `alive == 0` and launches it again
 //     (~20 us, once).  node_update / node_finish / the counter getters stop it first.
-// Results are those of the batch kernels for RAYTRACED: every Kolb kernel of the library evaluates a ray with the same device
-// functions.  THINLENS is evaluated in the reference's arithmetic (thin_ray_strict) in EVERY precision mode -- one lane has
+// Results are those of the batch kernels for RAYTRACED, bit for bit in STRICT and in FAST: every Kolb kernel of the library
+// evaluates a ray with the same device functions, the FAST arithmetic is written with explicit FMAs (fast_optics.hpp: the branchy
+// trace here and the unrolled trace of the batch kernels round alike) and a ray too close to call follows the listed kernel's rule
+// (tests/test_boundary_gpu.py: a fresh tid's first call == the one-ray batch launch on the same stream).  THINLENS is evaluated in the reference's arithmetic (thin_ray_strict) in EVERY precision mode -- one lane has
 // nothing to gain from the fast variant -- so under ZOIC_PRECISION_FAST with optical vignetting on, where the batch path runs
 // thin_refill.hip's fast arithmetic, a per-sample ray and a batch ray of the same sample can differ in low-order bits (never in
 // a decision: the fast vignetting test is decision-safe).  include/zoic_amd.h states this at zoic_camera_create_ray.
