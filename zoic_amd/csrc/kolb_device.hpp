@@ -135,7 +135,17 @@ __device__ __forceinline__ bool trace_lens_strict_pred(const KolbTable &T, V3 &o
         V3 N = normalize3_unit(nrm, r3);      // zoic.cpp:1010: the normal, normalised a second time
         oor |= alive & !(r0 & r1 & r2 & r3);   // a lane still alive HERE consumed these roots
         float c1 = -dot3(u, N);
-        float cs2 = static_cast<float>(static_cast<double>(S.eta * S.eta) * (1.0 - static_cast<double>(c1 * c1)));
+        // cs2 = (float)((double)(eta*eta) * (1.0 - (double)(c1*c1))), zoic.cpp:1016.  For c1^2 >= 1/32 the f64 difference has at most
+        // 29 significant bits and its f64 product with the 24-bit eta^2 is EXACT, so the conversion to float is the only rounding
+        // of eta^2 - eta^2 c1^2: one fmaf gives the same bits (no converts, no f64).  Grazing incidence (c1^2 < 1/32: the product
+        // may round in f64 first) takes the reference's expression, wave-uniformly.
+        const float c1sq = c1 * c1, eta2 = S.eta * S.eta;
+        float cs2 = __builtin_fmaf(-eta2, c1sq, eta2);
+        const bool grazing = !(c1sq >= 0.03125f);
+        if (__builtin_expect(__ballot(alive && grazing) != 0ull, 0)) {
+            const float cs2d = static_cast<float>(static_cast<double>(eta2) * (1.0 - static_cast<double>(c1sq)));
+            cs2 = grazing ? cs2d : cs2;
+        }
         const bool tirHere = (S.tirPossible != 0u) & (cs2 > 1.0f);
         tirSeen |= alive & !clipped & tirHere;
         alive &= !clipped & !tirHere;
