@@ -222,7 +222,10 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
                         tirTry = mask_bit(tirMask, lane) ? 1u : 0u;
                         unsure |= mask_bit(unsureMask, lane);
                         if (ok) { o = ot; d = dt; }
-                        else if (!unsure) { uint32_t ignored = 0; (void)trace_lens_fast_rolled(T, o, d, ignored); }   // the partial state of a failed try (only try 26's is ever handed out)
+                        else if (!unsure && k == static_cast<uint32_t>(kMaxTries) + 1u) {   // only try 26's partial state is ever handed out
+                            uint32_t ignored = 0;
+                            (void)trace_lens_fast_rolled(T, o, d, ignored);
+                        }
                     }
                 }
             } else if (fastTry) ok = trace_lens_fast_rolled(T, o, d, tirTry, &unsure);
