@@ -736,6 +736,15 @@ def main():
         return
 
     # ---- N = 1
+    if not args.no_sharded and not args.rays:
+        # the C-ABI's multi-device entry points (zoic_frame_*, csrc/frame.cpp) on the hardware this line comes from: ONE GPU listed
+        # twice -- slab partition, chunking, two compute streams + a copy stream per lane, the copy "gather" (same-device here) and
+        # the root-stream ordering all run as they would across devices; what it cannot show is xGMI
+        try:
+            line["frame_api"] = dict(single_process_frame_entry(torch, args.config, args.precision, [local_rank, local_rank], 5, 1),
+                                     note="zoic_frame_* with the one GPU listed twice: code path + bit-identity on hardware, not a scaling number")
+        except Exception as e:  # noqa: BLE001
+            line["frame_api"] = {"failed": str(e)[:200]}
     if not args.no_sharded:
         # north_star configs 4/5 on one GPU: nothing to gather, a slab is ONE launch (= the unsharded rates)
         line["sharded_frame"] = [sharded_frame_entry(torch, None, cname, dev, 0, 1, local_rank, st, args.gather_chunk_mb) for cname, st in (("C4", 5), ("C5", 2))]
