@@ -445,7 +445,7 @@ def single_process_frame_entry(torch, cfg_name, precision, devices, steps, warmu
         t_gather = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD))
         into_root = 28 * (n - (frame.slab(n, 0)[1] - frame.slab(n, 0)[0]))
         ent.update(with_gather=round(n * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3))
-        if len(devices) > 1:
+        if len(set(devices)) > 1:   # (a device listed twice copies to itself: no link involved)
             ingest = into_root * steps / t_gather / 1e9
             ent.update(root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((len(devices) - 1) * XGMI_LINK_GBS), 3))
         # the whole frame against ONE camera on the root device
