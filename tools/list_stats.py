@@ -24,6 +24,6 @@ for cfg in a.configs.split(","):
     cam.create_rays(s); torch.cuda.synchronize()
     lib.zoic_debug_pass_stats(out, 1)
     listed, triesAt, fin, triesFin = [int(v) for v in out[:4]]
-    print("%s rays %d: listed %d (%.3f%%), tries when listed %.2f on average; the STRICT kernel finished %d of them with %.2f tries on average"
+    print("%s rays %d: listed %d (%.3f%%), tries when listed %.2f on average; the listed kernel finished %d of them with %.2f tries on average"
           % (cfg, n, listed, 100.0 * listed / n, triesAt / max(listed, 1), fin, triesFin / max(fin, 1)))
     cam.close()

@@ -1,5 +1,5 @@
 """Summarise a tools/profile.sh output directory: kernel stats + PMC-derived rates of one camera_create_ray launch.
-A Kolb launch is a short pipeline of kernels (kolb_refill.hip: main kernel, heavy-list kernel, STRICT redo kernel): counters
+A Kolb launch is a short pipeline of kernels (kolb_pool_body.hpp main kernel + kolb_listed_body.hpp listed kernel): counters
 are averaged per dispatch for every kernel of the pipeline and then SUMMED over the pipeline, so every figure is per launch."""
 import collections, csv, glob, json, sys
 base, nrays = sys.argv[1], float(sys.argv[2])

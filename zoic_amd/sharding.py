@@ -5,7 +5,7 @@ bit-identical to the single-GPU frame.  The one exchange is the gather of the fi
 (torch.distributed: RCCL over xGMI on GPUs, gloo on CPU in the tests).
 
 The gather is pipelined against the trace: a rank cuts its slab into sub-launches of about `chunk_bytes`
-of payload, queued alternately on two compute streams (the end of one sub-launch -- its drain and the STRICT kernel over
+of payload, queued alternately on two compute streams (the end of one sub-launch -- its drain and the listed kernel over
 its work list -- runs under the next one's trace); as soon as sub-launch k is queued, its 28-byte payload (origin, dir,
 weight -- the flag word stays home) is posted to the root on the communication stream while sub-launch k+1 traces.  xGMI is point to point: every
 peer -> root transfer rides its own link, so the root ingests on up to 7 links at once; all sends/recvs of one round
@@ -102,7 +102,7 @@ class ShardedFrame:
         self.cuda = device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=device) if self.cuda else None
         # Sub-launches alternate between TWO compute streams: a Kolb launch ends with a drain (the pool's last rays at a few
-        # lanes per pass) and, in the decision-safe mode, with the STRICT kernel over its work list (a latency floor of
+        # lanes per pass) and, in the decision-safe mode, with the listed kernel over its work list (a latency floor of
         # ~0.1 ms); back to back on one stream, four sub-launches pay that four times (13-14 % of a C4 / C5 slab on one GPU in
         # round 2).  On alternating streams sub-launch k + 1 traces under the end of sub-launch k (every launch owns its
         # work cursors and work list: capi.cpp launch slots).
