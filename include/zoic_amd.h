@@ -36,11 +36,13 @@ extern "C" {
  *   1  round 1.
  *   2  round 2: zoic_create_rays_arnold, zoic_host_*, per-tid retry streams.
  *   3  round 3/4: zoic_lens_info gained the trailing fastRunsStrict (zoic_camera_get_info writes sizeof(zoic_lens_info) bytes:
- *      a v2 caller's struct is 4 bytes short); zoic_create_rays_arnold WRITES EVERY OUTPUT ROW WHOLE (v2 updated fields in
+ *      a v2 caller's struct is 8 bytes short, see the end of this entry); zoic_create_rays_arnold WRITES EVERY OUTPUT ROW WHOLE (v2 updated fields in
  *      place); zoic_camera_create_ray runs through a resident kernel, so a caller's hipDeviceSynchronize / hipFree can wait up
  *      to 50 ms for it to retire (zoic_camera_get_counters / _update / _destroy stop it first); the zoic_frame_* entry points
- *      (one frame over several devices of this process). */
-#define ZOIC_AMD_ABI_VERSION 3
+ *      (one frame over several devices of this process); zoic_lens_info gained precomputeTIR behind fastRunsStrict (8 bytes in all).
+ *   4  round 5: zoic_tile_* / zoic_camera_create_rays_tile (bucket-sized batches through the resident kernel, no launch);
+ *      zoic_frame_get_lane_info; ZOIC_FRAME_PAYLOAD_SPARSE; zoic_camera_set_frame_aspect.  Nothing of ABI 3 changed shape. */
+#define ZOIC_AMD_ABI_VERSION 4
 
 typedef enum zoic_status {
     ZOIC_OK = 0,
@@ -79,10 +81,11 @@ typedef enum zoic_precision {
        computation puts the sensor in FRONT of the rear vertex (originShift >= lenses[0].thickness) sends its rays away from
        the lens: the reference's one signed root (zoic.cpp:986, t < 0 never rejected) then lands far behind the ray, and the
        hit-point rounding no longer is small against the radii.  Such a camera (zoic_lens_info::fastRunsStrict) runs STRICT in
-       every mode.  So does a camera that fails zoic_camera_update's self-check: 4096 probe samples spread over the frame go
-       through the STRICT and the decision-safe FAST kernels, and the FAST modes are kept only if at most one of them is
-       decided differently and the direction RMSE of the others is < 1e-5 (0.3 ms per update; no counter, no retry stream is
-       touched). */
+       every mode.  So does a camera that fails zoic_camera_update's self-check: TWO slabs of 4096 probe samples each (two jitters
+       of a 64 x 64 lattice over sx in [-1, 1], sy in [-a, a], a = zoic_camera_set_frame_aspect's value, 1.0 by default) go through
+       the STRICT and the decision-safe FAST kernels, and the FAST modes are kept only if, on EACH slab, at most one ray is decided
+       differently and the direction RMSE of the others is < 5e-6 -- half of the 1e-5 tolerance (0.3 ms per update that rebuilds
+       tables; no counter, no retry stream is touched; a HIP failure inside the check is an error of the update). */
 } zoic_precision;
 
 #define ZOIC_MAX_LENS_SURFACES 32
@@ -171,6 +174,11 @@ zoic_status zoic_camera_set_bokeh_image(zoic_camera *cam, int width, int height,
 /* lens prescription text in memory instead of fopen(lensDataPath) (readTabularLensData, zoic.cpp:708-914) */
 zoic_status zoic_camera_set_lens_text(zoic_camera *cam, const char *text, size_t len);
 zoic_status zoic_camera_set_precision(zoic_camera *cam, zoic_precision mode);
+/* The largest |sy| the renderer will send (Arnold's convention: sx in [-1, 1], sy in [-1/aspect, 1/aspect]): the extent
+ * of the frame zoic_camera_update's self-check of the FAST modes spreads its probe samples over.  Default 1.0 (a square frame; a
+ * 3:2 frame is inside it); a portrait frame passes its own 1/aspect > 1.  Takes effect at the next update that rebuilds tables
+ * (or at once for the verdict of the next update when the value changed). */
+zoic_status zoic_camera_set_frame_aspect(zoic_camera *cam, float max_abs_sy);
 /* seed of the per-ray retry streams (see zoic_create_rays_device) */
 zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed);
 
@@ -211,6 +219,36 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
  * arithmetic, so the same sample can differ in low-order bits between the two (decisions never differ). */
 zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output,
                                    uint16_t tid);
+/* ---- tiles: what a render thread buffers of camera_create_ray (zoic.cpp:1752), answered without a launch --------------------
+ * A renderer works in buckets (Arnold: 64 x 64 pixels x AA^2 samples = 36 K ... 150 K samples per bucket and thread).  Served by
+ * kernel launches such a batch costs 50-80 us of launch, stream and copy overhead whatever it carries; a zoic_tile goes to the
+ * camera's RESIDENT kernel instead (csrc/mailbox.hip): the request is one 64-byte line in mapped page-locked memory, the kernel's
+ * worker waves take 64 samples each at full lane width -- the same device functions, hence the same bits, as the batch kernels --
+ * read the AtCameraInput rows and write the AtCameraOutput rows in place across PCIe, and the render thread spins on one word.
+ *   zoic_tile_create  page-locked input / output arrays of `capacity` rows (<= ZOIC_TILE_MAX_SAMPLES) for render thread `tid`
+ *                     (tile requests of tids 64 apart share a mailbox slot and are served one after the other);
+ *   zoic_tile_inputs / _outputs   the arrays: the caller fills inputs[0 .. n) (the fields zoic reads: sx, sy, lensx, lensy);
+ *   zoic_tile_submit  posts rows [0, n) and returns at once; ray i draws its retries from the stream keyed by
+ *                     ray_index_base + i, exactly as zoic_create_rays_arnold does: outputs[i] equals that call's row bit for bit
+ *                     (whole rows: origin, dir, weight[3], dOdy / dDdy for retried rays, zeros elsewhere);
+ *   zoic_tile_wait    returns when outputs[0 .. n) are complete; zoic_tile_done polls (1 = complete, nothing pending).
+ * One submit per tile at a time (a second submit waits for the first).  A tile belongs to one render thread; different tiles may
+ * be used from different threads at once.  zoic_camera_update / _destroy: wait for (or destroy) the camera's tiles first.
+ * zoic_camera_create_rays_tile is the one-call form for arrays the caller owns: page-locked mapped arrays (zoic_host_alloc /
+ * zoic_host_register) are used in place, anything else is staged through the slot's own page-locked buffers (two 16 Ki-row
+ * pieces in flight).  Any n.  Counters: tile rays count like every other ray. */
+#define ZOIC_TILE_MAX_SAMPLES 65536u
+typedef struct zoic_tile zoic_tile;
+zoic_status zoic_tile_create(zoic_camera *cam, uint32_t capacity, uint16_t tid, zoic_tile **out);
+void        zoic_tile_destroy(zoic_tile *tile);
+zoic_camera_input  *zoic_tile_inputs(zoic_tile *tile);
+zoic_camera_output *zoic_tile_outputs(zoic_tile *tile);
+uint32_t    zoic_tile_capacity(const zoic_tile *tile);
+zoic_status zoic_tile_submit(zoic_tile *tile, uint32_t n, uint64_t ray_index_base);
+zoic_status zoic_tile_wait(zoic_tile *tile);
+int         zoic_tile_done(zoic_tile *tile);
+zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,
+                                         uint64_t ray_index_base, uint16_t tid);
 /* camera_reverse_ray, zoic.cpp:1992-1995: the reference returns false and writes nothing; so does this (returns 0). */
 int zoic_camera_reverse_ray(const zoic_camera *cam, const zoic_vec3 *Po, float fov, float *Ps /* [2] */,
                             float *relative_time);
@@ -263,7 +301,8 @@ zoic_status zoic_frame_set_lens_text(zoic_frame *frame, const char *text, size_t
 zoic_status zoic_frame_set_precision(zoic_frame *frame, zoic_precision mode);
 zoic_status zoic_frame_set_seed(zoic_frame *frame, uint32_t seed);
 zoic_status zoic_frame_update(zoic_frame *frame, const zoic_params *p);
-/* rays per chunk of a peer's slab (rounded down to 256-ray tiles); 0 = default: a quarter of a slab, at least 64 MB of payload */
+/* rays per chunk of a peer's slab (rounded down to 256-ray tiles); 0 = default: a quarter of a slab, at least 64 MB of payload.
+ * A slab is never cut into more than 64 chunks: a smaller value is raised to what gives 64. */
 zoic_status zoic_frame_set_chunk_rays(zoic_frame *frame, uint64_t rays);
 /* camera_create_ray over n samples resident on the devices.
  *   d_samples : n_devices pointers; d_samples[i] = device i's slab, (end - begin) x (sx, sy, lensx, lensy) f32 in device i's
@@ -284,6 +323,16 @@ zoic_status zoic_frame_render_host(zoic_frame *frame, uint64_t n, const float *h
 zoic_status zoic_frame_generate_samples(zoic_frame *frame, uint64_t n, uint64_t ray_index_base, uint32_t width, uint32_t height,
                                         uint32_t spp, uint32_t seed);
 zoic_status zoic_frame_synchronize(zoic_frame *frame);      /* every stream of the frame, on every device */
+/* What device i's lane did in the last zoic_frame_render_device call, and how it reaches the root: peer_access_* = 1 when
+ * hipDeviceCanAccessPeer said yes AND hipDeviceEnablePeerAccess succeeded in that direction (0: hipMemcpyPeerAsync stages through
+ * the host -- correct, slow; the root itself and a device listed twice report 1: no link involved). */
+typedef struct zoic_frame_lane_info {
+    int32_t device, peer_access_to_root, peer_access_from_root;
+    uint32_t chunks;              /* sub-launches of the slab */
+    uint64_t rays;                /* the slab */
+    uint64_t bytes_to_root;       /* bytes the lane's copies moved into the root's memory (0 for the root's own slab) */
+} zoic_frame_lane_info;
+zoic_status zoic_frame_get_lane_info(const zoic_frame *frame, int i, zoic_frame_lane_info *out);
 zoic_status zoic_frame_get_counters(zoic_frame *frame, zoic_counters *sum);   /* summed over the devices */
 
 /* ---- statistics (node_finish prints them, zoic.cpp:1729-1732) ------------------------------ */

@@ -1,0 +1,239 @@
+"""The resident tile server (zoic_tile_* / zoic_camera_create_rays_tile, csrc/mailbox.hip): what a render thread buffers of
+camera_create_ray (zoic.cpp:1752) -- a bucket of samples -- answered WITHOUT a kernel launch.  The bar: a tile's AtCameraOutput
+rows equal zoic_create_rays_arnold's rows for the same samples and ray indices BIT FOR BIT, in STRICT and in FAST, on every
+configuration; and STRICT rows equal the oracle's.  Everything goes through ctypes -> libzoic_amd.so (the C-ABI)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from zoic_amd import PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, PinnedArray, ZoicCamera, ZoicError
+from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_rng_states, synthetic_samples
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def camera(cfg, precision, **override):
+    cam = ZoicCamera(0)
+    if CONFIGS[cfg]["bokeh"]:
+        cam.set_bokeh_image(hexagon_bokeh())
+    cam.update(**dict(camera_params(cfg), **override))
+    cam.set_precision(precision)
+    return cam
+
+
+def inputs_of(cfg, n, where):
+    """(n, 7) AtCameraInput rows of a slab of the config's frame starting at row `where` (0..1) + its global ray index base."""
+    c = CONFIGS[cfg]
+    base = int(c["width"] * int(c["height"] * where)) * c["spp"]
+    s = synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1, ray_index_base=base)
+    a = np.zeros((n, 7), np.float32)
+    a[:, 0], a[:, 1], a[:, 4], a[:, 5] = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
+    a[:, 2], a[:, 3], a[:, 6] = 0.25, -0.5, 0.125     # dsx, dsy, relative_time: zoic reads none of them
+    return a, s, base
+
+
+def same_rows(a, b):
+    a, b = bits(a), bits(b)
+    nan = np.isnan(a.view(np.float32)) & np.isnan(b.view(np.float32))
+    return bool(((a == b) | nan).all())
+
+
+@pytest.mark.parametrize("cfg,where", [("C1", 0.4), ("C2", 0.08), ("C3", 0.3), ("C4", 0.5), ("C5", 0.12)])
+@pytest.mark.parametrize("precision", [PRECISION_STRICT, PRECISION_FAST])
+def test_a_tile_equals_the_arnold_batch_call_bit_for_bit(gpu, cfg, where, precision):
+    """n in {1, 63, 64, 65, 4096, 65536}: one lane, a ragged batch, a full batch, one lane over, a bucket, the largest tile --
+    against zoic_create_rays_arnold (launch-based: GUARD + listed kernels in FAST) on the same samples and ray indices.  The slabs
+    hold first-try rays, retried rays, retry-dead rays (C2, C5), dead pixels (C5) and rays the FAST mode cannot decide (C4)."""
+    cam = camera(cfg, precision)
+    a, _s, base = inputs_of(cfg, 65536, where)
+    ref = cam.create_rays_arnold(a, ray_index_base=base)
+    assert (ref[:, 18] == 0).any() or cfg in ("C1", "C3", "C4")
+    before = cam.counters()
+    tile = cam.tile(65536, tid=5)
+    done = 0
+    for n in (1, 63, 64, 65, 4096, 65536):
+        tile.outputs[:] = np.float32(7.0)                      # whole rows are written: nothing of this survives in [0, n)
+        tile.inputs[:n] = a[:n]
+        tile.submit(n, base)
+        tile.wait()
+        assert same_rows(tile.outputs[:n], ref[:n]), (cfg, precision, n, np.nonzero((bits(tile.outputs[:n]) != bits(ref[:n])).any(1))[0][:5])
+        assert (tile.outputs[n:n + 8] == 7.0).all()            # ... and nothing beyond row n is touched
+        done += n
+    after = cam.counters()
+    if cfg != "C1":
+        assert after["succesRays"] + after["vignettedRays"] - before["succesRays"] - before["vignettedRays"] == done
+    tile.close()
+    cam.close()
+
+
+@pytest.mark.parametrize("cfg,where", [("C2", 0.08), ("C3", 0.3), ("C5", 0.12), ("C1", 0.4)])
+def test_a_strict_tile_equals_the_oracle(gpu, oracle_lib, cfg, where):
+    """No intermediary: STRICT tile rows against the oracle's rays (per-ray streams keyed by the global ray index), counters too."""
+    cam = camera(cfg, PRECISION_STRICT)
+    oc = oracle_lib.OracleCamera()
+    if CONFIGS[cfg]["bokeh"]:
+        oc.set_bokeh_image(hexagon_bokeh())
+    oc.update(**camera_params(cfg))
+    n = 20000 + 37
+    a, s, base = inputs_of(cfg, n, where)
+    ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=1, ray_index_base=base))
+    cam.reset_counters()
+    out = cam.create_rays_tile(a, ray_index_base=base, tid=2)
+    assert np.array_equal(bits(out[:, 0:3].T.copy()), bits(ref["origin"]))
+    assert np.array_equal(bits(out[:, 3:6].T.copy()), bits(ref["dir"]))
+    assert np.array_equal(out[:, 18], ref["weight"]) and np.array_equal(out[:, 19], ref["weight"]) and np.array_equal(out[:, 20], ref["weight"])
+    retried = (ref["flags"] & 1) != 0
+    assert np.array_equal(bits(out[retried, 9:12]), bits(out[retried, 0:3])) and np.array_equal(bits(out[retried, 15:18]), bits(out[retried, 3:6]))
+    assert (out[~retried, 9:12] == 0).all() and (out[:, 6:9] == 0).all() and (out[:, 12:15] == 0).all()
+    c = cam.counters()
+    if cfg != "C1":
+        assert c["vignettedRays"] == int((ref["tries"] > 25).sum()) and c["succesRays"] == n - c["vignettedRays"]
+    cam.close()
+
+
+@pytest.mark.parametrize("precision", [PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_UNCHECKED])
+def test_thin_lens_tiles_with_optical_vignetting_and_an_image(gpu, precision):
+    """THINLENS with the retry loop on (zoic.cpp:1804-1819) behind a bokeh image: the batch path runs thin_refill.hip (FAST: its fast
+    arithmetic), a tile the same per-ray functions."""
+    for image in (False, True):
+        cam = ZoicCamera(0)
+        if image:
+            cam.set_bokeh_image(hexagon_bokeh(64))
+        cam.update(**dict(camera_params("C1"), opticalVignettingDistance=5.0, opticalVignettingRadius=0.7, useImage=image, bokehPath="mem:hex64" if image else ""))
+        cam.set_precision(precision)
+        a, _s, base = inputs_of("C1", 30000, 0.1)
+        ref = cam.create_rays_arnold(a, ray_index_base=base)
+        assert 0.02 < (ref[:, 18] == 0).mean() < 0.98 or image
+        out = cam.create_rays_tile(a, ray_index_base=base, tid=9)
+        assert same_rows(out, ref), (precision, image)
+        cam.close()
+
+
+def test_create_rays_tile_with_pageable_and_page_locked_arrays_of_any_size(gpu):
+    """The one-call form: numpy arrays are staged through the slot's page-locked buffers (two 16 Ki-row pieces in flight), page-locked
+    arrays are used in place (65536-row requests); 100 003 rows cross every boundary of both."""
+    cam = camera("C3", PRECISION_FAST)
+    n = 100_003
+    a, _s, base = inputs_of("C3", n, 0.6)
+    ref = cam.create_rays_arnold(a, ray_index_base=base)
+    out = cam.create_rays_tile(a, ray_index_base=base, tid=1)
+    assert same_rows(out, ref)
+    pi, po = PinnedArray((n, 7), np.float32), PinnedArray((n, 21), np.float32)
+    pi.array[:] = a
+    po.array[:] = 3.0
+    got = cam.create_rays_tile(pi.array, ray_index_base=base, tid=1, out=po.array)
+    assert got is po.array and same_rows(po.array, ref)
+    # a small request after a large one on the same slot; and an empty one
+    out = cam.create_rays_tile(a[:17], ray_index_base=base, tid=1)
+    assert same_rows(out, ref[:17])
+    assert cam.create_rays_tile(a[:0], ray_index_base=base, tid=1).shape == (0, 21)
+    pi.free()
+    po.free()
+    cam.close()
+
+
+def test_sixteen_render_threads_with_a_tile_each_equal_the_batch_call(gpu):
+    """16 threads x 12 buckets of 64 x 64 x 4 samples on ONE camera at once (ctypes releases the GIL around the calls), tids 0..15
+    plus two threads sharing slots with them (tid 64 + k): every tile equals the batch call on its samples."""
+    cam = camera("C2", PRECISION_FAST)
+    per = 64 * 64 * 4
+    a, _s, base = inputs_of("C2", per * 12, 0.05)
+    ref = cam.create_rays_arnold(a, ray_index_base=base)
+    errors = []
+
+    def run(tid):
+        try:
+            tile = cam.tile(per, tid=tid)
+            for k in range(12):
+                kk = (k + tid) % 12
+                tile.inputs[:per] = a[kk * per:(kk + 1) * per]
+                tile.submit(per, base + kk * per)
+                if k % 3 == 0:
+                    time.sleep(0.0005)                   # the tile finishes (or the kernel retires) while nobody is waiting
+                assert tile.done() in (True, False)
+                tile.wait()
+                if not same_rows(tile.outputs[:per], ref[kk * per:(kk + 1) * per]):
+                    errors.append((tid, k))
+            tile.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+    threads = [threading.Thread(target=run, args=(t,)) for t in list(range(16)) + [64 + 3, 64 + 7]]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:4]
+    cam.close()
+
+
+def test_tiles_per_sample_calls_updates_and_retirements_interleave(gpu):
+    """One render thread mixes per-sample calls and tiles on ONE slot; the resident kernel retires in between (1 ms idle), is started
+    again with more slots, survives a precision change, a seed change (the tile's per-ray streams are keyed by it) and a node_update."""
+    cam = camera("C2", PRECISION_STRICT)
+    a, s, base = inputs_of("C2", 4096, 0.08)
+    ref = cam.create_rays_arnold(a, ray_index_base=base)
+    tile = cam.tile(4096, tid=3)
+    one = cam.create_ray(*[float(v) for v in s[0]], tid=3)          # the per-sample kernel starts WITHOUT workers ...
+    tile.inputs[:] = a
+    tile.submit(4096, base)                                          # ... and is started again with them
+    two = cam.create_ray(*[float(v) for v in s[0]], tid=3)          # same slot: waits for the tile, then runs
+    assert tile.done()
+    tile.wait()
+    assert same_rows(tile.outputs, ref)
+    assert (one.origin.x, one.origin.y) == (two.origin.x, two.origin.y) or one.weight[0] == 0 or two.weight[0] == 0   # same sample, same sensor point
+    time.sleep(0.01)                                                 # the kernel has retired by now
+    out = cam.create_rays_tile(a, ray_index_base=base, tid=40)       # a new slot: restart watching 41 slots
+    assert same_rows(out, ref)
+    cam.set_precision(PRECISION_FAST)
+    ref_fast = cam.create_rays_arnold(a, ray_index_base=base)
+    tile.submit(4096, base)
+    tile.wait()
+    assert same_rows(tile.outputs, ref_fast)
+    cam.set_seed(77)
+    ref_seed = cam.create_rays_arnold(a, ray_index_base=base)
+    assert not same_rows(ref_seed, ref_fast)                         # retried rays draw other numbers
+    tile.submit(4096, base)
+    tile.wait()
+    assert same_rows(tile.outputs, ref_seed)
+    cam.update(**dict(camera_params("C2"), fStop=5.6))
+    ref_f56 = cam.create_rays_arnold(a, ray_index_base=base)
+    tile.submit(4096, base)
+    tile.wait()
+    assert same_rows(tile.outputs, ref_f56)
+    # counters: a tile's rays are counted like every other ray's
+    cam.reset_counters()
+    tile.submit(4096, base)
+    tile.wait()
+    c = cam.counters()
+    assert c["succesRays"] + c["vignettedRays"] == 4096 and c["vignettedRays"] == int((ref_f56[:, 18] == 0).sum())
+    tile.close()
+    cam.close()
+
+
+def test_tile_argument_errors(gpu):
+    cam = ZoicCamera(0)
+    with pytest.raises(ZoicError) as e:
+        cam.tile(0)
+    assert e.value.status_name == "ZOIC_ERR_INVALID_ARGUMENT"
+    with pytest.raises(ZoicError):
+        cam.tile(65537)
+    tile = cam.tile(128)
+    with pytest.raises(ZoicError) as e:
+        tile.submit(64, 0)                                           # before a successful update
+    assert e.value.status_name == "ZOIC_ERR_NOT_UPDATED"
+    cam.update(**camera_params("C2"))
+    with pytest.raises(ZoicError) as e:
+        tile.submit(129, 0)
+    assert e.value.status_name == "ZOIC_ERR_INVALID_ARGUMENT"
+    tile.submit(0, 0)
+    tile.wait()
+    tile.wait()                                                      # nothing pending: returns at once
+    assert tile.done()
+    tile.close()
+    cam.close()

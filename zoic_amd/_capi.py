@@ -9,13 +9,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ZOIC_AMD_LIB points at another build of the same library (A/B experiments, tools/); there is still no fallback
 LIB_PATH = os.environ.get("ZOIC_AMD_LIB") or os.path.join(HERE, "libzoic_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LENS_SURFACES = 32
 LUT_ENTRIES = 32
 
 THINLENS, RAYTRACED, LENS_NONE = 0, 1, 2
 PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_UNCHECKED = 0, 1, 2
-FRAME_RECORDS, FRAME_PAYLOAD = 0, 1
+FRAME_RECORDS, FRAME_PAYLOAD, FRAME_PAYLOAD_SPARSE = 0, 1, 2
+TILE_MAX_SAMPLES = 65536
 
 STATUS_NAMES = ["ZOIC_OK", "ZOIC_ERR_INVALID_ARGUMENT", "ZOIC_ERR_LENS_PATH", "ZOIC_ERR_LENS_COLUMNS",
                 "ZOIC_ERR_LENS_PARSE", "ZOIC_ERR_MULTI_APERTURE", "ZOIC_ERR_NO_APERTURE", "ZOIC_ERR_TOO_MANY_LENSES",
@@ -51,6 +52,11 @@ RAY_DTYPE = [("ox", "<f4"), ("oy", "<f4"), ("oz", "<f4"), ("dx", "<f4"), ("dy", 
              ("flags", "<u4")]
 
 
+class FrameLaneInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("peer_access_to_root", C.c_int32), ("peer_access_from_root", C.c_int32), ("chunks", C.c_uint32),
+                ("rays", C.c_uint64), ("bytes_to_root", C.c_uint64)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("succesRays", "vignettedRays", "totalInternalReflection")]
 
@@ -81,11 +87,21 @@ SYMBOLS = {
     "zoic_camera_set_bokeh_image": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "zoic_camera_set_lens_text": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "zoic_camera_set_precision": (C.c_int, [_vp, C.c_int]),
+    "zoic_camera_set_frame_aspect": (C.c_int, [_vp, C.c_float]),
     "zoic_camera_set_seed": (C.c_int, [_vp, _u32]),
     "zoic_create_rays_device": (C.c_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "zoic_create_rays_host": (C.c_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
     "zoic_create_rays_arnold": (C.c_int, [_vp, _u64, C.POINTER(CameraInput), C.POINTER(CameraOutput), _u64]),
     "zoic_camera_create_ray": (C.c_int, [_vp, C.POINTER(CameraInput), C.POINTER(CameraOutput), C.c_uint16]),
+    "zoic_tile_create": (C.c_int, [_vp, _u32, C.c_uint16, C.POINTER(_vp)]),
+    "zoic_tile_destroy": (None, [_vp]),
+    "zoic_tile_inputs": (C.POINTER(CameraInput), [_vp]),
+    "zoic_tile_outputs": (C.POINTER(CameraOutput), [_vp]),
+    "zoic_tile_capacity": (_u32, [_vp]),
+    "zoic_tile_submit": (C.c_int, [_vp, _u32, _u64]),
+    "zoic_tile_wait": (C.c_int, [_vp]),
+    "zoic_tile_done": (C.c_int, [_vp]),
+    "zoic_camera_create_rays_tile": (C.c_int, [_vp, _u32, C.POINTER(CameraInput), C.POINTER(CameraOutput), _u64, C.c_uint16]),
     "zoic_camera_reverse_ray": (C.c_int, [_vp, C.POINTER(Vec3), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "zoic_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "zoic_host_free": (None, [_vp]),
@@ -108,6 +124,7 @@ SYMBOLS = {
     "zoic_frame_render_host": (C.c_int, [_vp, _u64, _vp, _u64, _vp]),
     "zoic_frame_generate_samples": (C.c_int, [_vp, _u64, _u64, _u32, _u32, _u32, _u32]),
     "zoic_frame_synchronize": (C.c_int, [_vp]),
+    "zoic_frame_get_lane_info": (C.c_int, [_vp, C.c_int, C.POINTER(FrameLaneInfo)]),
     "zoic_frame_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "zoic_camera_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "zoic_camera_reset_counters": (C.c_int, [_vp]),

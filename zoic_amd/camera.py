@@ -89,6 +89,52 @@ class PinnedArray:
             pass
 
 
+class ZoicTile:
+    """A render thread's bucket of samples (zoic_tile_*): page-locked AtCameraInput / AtCameraOutput arrays the camera's
+    RESIDENT kernel reads and writes in place -- no launch, no stream, no copy.
+
+        tile = cam.tile(capacity=64 * 64 * 16, tid=3)
+        tile.inputs[:n, (0, 1, 4, 5)] = samples       # (capacity, 7) float32 view: sx sy dsx dsy lensx lensy relative_time
+        tile.submit(n, ray_index_base)                # returns at once
+        tile.wait()                                   # tile.outputs[:n] -- (capacity, 21) float32 AtCameraOutput rows -- are complete
+    Row i equals zoic_create_rays_arnold's row for the same sample and ray index, bit for bit."""
+
+    def __init__(self, cam, capacity, tid=0):
+        self._cam = cam
+        self._lib = cam._lib
+        h = C.c_void_p()
+        self._h = None
+        cam._check(self._lib.zoic_tile_create(cam._h, int(capacity), int(tid) & 0xFFFF, C.byref(h)))
+        self._h = h
+        self.capacity = int(self._lib.zoic_tile_capacity(h))
+        self.tid = int(tid)
+        pin = C.cast(self._lib.zoic_tile_inputs(h), C.c_void_p).value
+        pout = C.cast(self._lib.zoic_tile_outputs(h), C.c_void_p).value
+        self.inputs = np.frombuffer((C.c_char * (self.capacity * 28)).from_address(pin), dtype=np.float32).reshape(self.capacity, 7)
+        self.outputs = np.frombuffer((C.c_char * (self.capacity * 84)).from_address(pout), dtype=np.float32).reshape(self.capacity, 21)
+
+    def submit(self, n, ray_index_base=0):
+        self._cam._check(self._lib.zoic_tile_submit(self._h, int(n), int(ray_index_base)))
+
+    def wait(self):
+        self._cam._check(self._lib.zoic_tile_wait(self._h))
+
+    def done(self):
+        return bool(self._lib.zoic_tile_done(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.inputs = self.outputs = None
+            self._lib.zoic_tile_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ZoicCamera:
     def __init__(self, device=0):
         self._lib = _capi.load()
@@ -142,6 +188,10 @@ class ZoicCamera:
 
     def set_seed(self, seed):
         self._check(self._lib.zoic_camera_set_seed(self._h, int(seed) & 0xFFFFFFFF))
+
+    def set_frame_aspect(self, max_abs_sy):
+        """The largest |sy| the renderer sends (1/aspect): the extent node_update's self-check of the FAST modes probes."""
+        self._check(self._lib.zoic_camera_set_frame_aspect(self._h, float(max_abs_sy)))
 
     def update(self, **kw):
         unknown = set(kw) - set(DEFAULTS)
@@ -248,6 +298,20 @@ class ZoicCamera:
         outs[:, 18:21] = 1.0
         self._check(self._lib.zoic_create_rays_arnold(self._h, n, a.ctypes.data_as(C.POINTER(_capi.CameraInput)),
                                                       outs.ctypes.data_as(C.POINTER(_capi.CameraOutput)), int(ray_index_base)))
+        return outs
+
+    def tile(self, capacity, tid=0):
+        """A ZoicTile of this camera (destroy it -- tile.close() -- before the camera)."""
+        return ZoicTile(self, capacity, tid)
+
+    def create_rays_tile(self, inputs, ray_index_base=0, tid=0, out=None):
+        """(n,7) float32 AtCameraInput rows -> (n,21) float32 AtCameraOutput rows through the resident kernel
+        (zoic_camera_create_rays_tile): page-locked arrays (PinnedArray) are used in place, numpy arrays are staged."""
+        a = inputs if (isinstance(inputs, np.ndarray) and inputs.dtype == np.float32 and inputs.flags.c_contiguous) else np.ascontiguousarray(inputs, dtype=np.float32)
+        n = a.shape[0]
+        outs = out if out is not None else np.empty((n, 21), dtype=np.float32)
+        self._check(self._lib.zoic_camera_create_rays_tile(self._h, n, a.ctypes.data_as(C.POINTER(_capi.CameraInput)),
+                                                           outs.ctypes.data_as(C.POINTER(_capi.CameraOutput)), int(ray_index_base), int(tid) & 0xFFFF))
         return outs
 
     def generate_samples(self, n, width, height, spp, seed=1, ray_index_base=0, out=None, stream=None):

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +37,8 @@
 #pragma STDC FP_CONTRACT OFF
 
 using namespace zoic;
+
+struct zoic_tile;
 
 namespace {
 
@@ -148,38 +151,44 @@ struct CallContext {
     }
 };
 
-// The per-sample mailbox (mailbox.hip): header + 64 requests + 64 replies in ONE mapped, page-locked allocation, the
-// sequence numbers the resident kernel has answered in device memory (they survive its retirements), a private stream.
+// The mailbox of the resident kernel (mailbox.hip): header + 64 request lines + 64 reply lines + 64 tile-done lines in ONE mapped,
+// page-locked allocation; the launch's device-side state (what each slot has answered, the control block, the tile jobs: they
+// survive its retirements); a private stream.
 struct Mailbox {
     std::mutex launchM;                        // launch / stop of the resident kernel
     PinnedBuffer mem;
-    uint32_t *dServed = nullptr;
+    MailDeviceState *dState = nullptr;
     hipStream_t stream = nullptr;
     std::mutex slotM[kMailSlots];              // one call per slot at a time (tids 64 apart share a slot)
     uint32_t seq[kMailSlots] = {};
+    uint32_t tileSeq[kMailSlots] = {};         // the tile in flight on the slot (0: none); under slotM
     std::atomic<uint32_t> slotsInUse{0};       // slots the resident launch watches; written under launchM (0: not initialised)
+    std::atomic<uint32_t> workerGroups{0};     // tile worker workgroups of the resident launch (0 until the camera sees its first tile)
+    zoic_tile *ownTile[kMailSlots][2] = {};    // zoic_camera_create_rays_tile's staging for callers' pageable arrays (under slotM)
     volatile MailHeader *header() const { return static_cast<volatile MailHeader *>(mem.host); }
-    volatile MailRequest *request(unsigned slot) const { return reinterpret_cast<volatile MailRequest *>(static_cast<char *>(mem.host) + 64) + slot; }
-    volatile MailReply *reply(unsigned slot) const { return reinterpret_cast<volatile MailReply *>(static_cast<char *>(mem.host) + 64 + 64 * kMailSlots) + slot; }
+    volatile MailRequest *request(unsigned slot) const { return reinterpret_cast<volatile MailRequest *>(static_cast<char *>(mem.host) + kMailRequestsOffset) + slot; }
+    volatile MailReply *reply(unsigned slot) const { return reinterpret_cast<volatile MailReply *>(static_cast<char *>(mem.host) + kMailRepliesOffset) + slot; }
+    volatile MailTileDone *tile_done(unsigned slot) const { return reinterpret_cast<volatile MailTileDone *>(static_cast<char *>(mem.host) + kMailTileDoneOffset) + slot; }
     hipError_t init()
     {
-        if (mem.host && dServed && stream) return hipSuccess;
-        // all or nothing: a half-built mailbox (no dServed, the null stream) must never reach a launch -- the next call retries
-        hipError_t e = mem.reserve(64 + 2 * 64 * kMailSlots);
+        if (mem.host && dState && stream) return hipSuccess;
+        // all or nothing: a half-built mailbox (no device state, the null stream) must never reach a launch -- the next call retries
+        hipError_t e = mem.reserve(kMailBytes);
         if (e == hipSuccess) {
             std::memset(mem.host, 0, mem.cap);
-            if (!dServed) e = hipMalloc(reinterpret_cast<void **>(&dServed), (kMailSlots + 4) * sizeof(uint32_t));   // + the launch's control block
+            if (!dState) e = hipMalloc(reinterpret_cast<void **>(&dState), sizeof(MailDeviceState));
         }
-        if (e == hipSuccess) e = hipMemset(dServed, 0, (kMailSlots + 4) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(dState, 0, sizeof(MailDeviceState));
         if (e == hipSuccess && !stream) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
-            if (dServed) { (void)hipFree(dServed); dServed = nullptr; }
+            if (dState) { (void)hipFree(dState); dState = nullptr; }
             mem.release();
         }
         return e;
     }
-    // the resident kernel retires (adding its ray counters to the camera's) and nothing of it is left in flight
+    // the resident kernel retires (adding its ray counters to the camera's) and nothing of it is left in flight; a tile it was
+    // working on is finished first (mailbox.hip: no wave leaves with a batch in hand)
     hipError_t stop()
     {
         std::lock_guard<std::mutex> lk(launchM);
@@ -191,13 +200,7 @@ struct Mailbox {
         header()->alive = 0u;
         return e;
     }
-    void release()
-    {
-        (void)stop();
-        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
-        if (dServed) { (void)hipFree(dServed); dServed = nullptr; }
-        mem.release();
-    }
+    void release();
 };
 
 // camera_create_ray's `tid` (zoic.cpp:1752): one retry stream per render thread, advanced by every call that retries.
@@ -218,6 +221,7 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     Rng stream{};                  // the xor128 function-static state (zoic.cpp:648): LUT build draws from it
     zoic_precision precision = ZOIC_PRECISION_STRICT;
     bool fastVerdict = false, fastVerdictValid = false;   // fast_self_check's answer for the tables the camera holds now
+    float frameMaxSy = 1.0f;  // zoic_camera_set_frame_aspect: the self-check's probe lattice covers sy in [-frameMaxSy, frameMaxSy]
     bool fastDomain = true;   // RAYTRACED: the lens is inside the FAST modes' domain (include/zoic_amd.h, zoic_precision); else every mode runs STRICT
     // kernel mode of a launch: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked
     int kernel_mode() const
@@ -301,6 +305,29 @@ void zoic_camera::return_context(CallContext *c)
 {
     std::lock_guard<std::mutex> lk(poolM);
     freeContexts.push_back(c);
+}
+
+// zoic_tile (include/zoic_amd.h): a render thread's bucket of samples -- page-locked AtCameraInput / AtCameraOutput arrays the GPU
+// reads and writes in place -- bound to the mailbox slot of its tid.
+struct zoic_tile {
+    zoic_camera *cam = nullptr;
+    uint16_t tid = 0;
+    unsigned slot = 0;
+    uint32_t capacity = 0;
+    PinnedBuffer mem;                 // [capacity x 28 B inputs][pad to 64][capacity x 84 B outputs]
+    zoic_camera_input *inputs = nullptr;
+    zoic_camera_output *outputs = nullptr;
+    uint64_t dIn = 0, dOut = 0;       // the same arrays as the device sees them
+    uint32_t seq = 0;                 // the submit not waited for yet (0: none); under the slot's mutex
+};
+
+void Mailbox::release()
+{
+    (void)stop();
+    for (auto &pair : ownTile) for (zoic_tile *&t : pair) if (t) { t->mem.release(); delete t; t = nullptr; }
+    if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    if (dState) { (void)hipFree(dState); dState = nullptr; }
+    mem.release();
 }
 
 namespace {
@@ -631,7 +658,7 @@ inline void expand_record(const zoic_ray &r, zoic_camera_output &o)
 
 // node_update's self-check of the FAST modes (RAYTRACED): kFastProbeRays samples spread over the frame go through the STRICT and
 // the decision-safe FAST kernels; the camera keeps its FAST modes only if FAST decides these rays as STRICT does (one flip at
-// most) and its directions are within north_star's tolerance (RMSE < 1e-5 over the rays with weight).  FAST drops the
+// most) and its directions are well within north_star's tolerance (RMSE < 5e-6 over the rays with weight, per slab).  FAST drops the
 // reference's renormalisations and takes cos(i) from the hit's geometry (fast_optics.hpp): exact on a lens laid out like a
 // lens, not on every table of numbers -- a prescription whose elements graze (a fisheye with an element removed: 6e-5) runs
 // STRICT instead.  No counter is touched, no retry stream advanced (per-ray streams of the probe's own ray indices).
@@ -650,11 +677,11 @@ zoic_status fast_self_check(zoic_camera *cam, bool &keep)
     ZOIC_HIP(cam->dFastProbeRays.reserve(2 * nAll));
     if (!cam->fastProbeReady) {
         std::vector<float> h(nAll * 4);
-        for (uint32_t k = 0; k < nAll; ++k) {   // per slab: a jittered 64 x 64 lattice over sx in [-1, 1], sy in [-2/3, 2/3]
+        for (uint32_t k = 0; k < nAll; ++k) {   // per slab: a jittered 64 x 64 lattice over sx in [-1, 1], sy in [-frameMaxSy, frameMaxSy]
             const uint32_t i = k % kFastProbeRays;
             const auto u01 = [](uint32_t v) { return static_cast<float>(pcg_hash(v) >> 8) * (1.0f / 16777216.0f); };
             h[4 * k + 0] = ((static_cast<float>(i & 63u) + u01(4 * k)) / 64.0f) * 2.0f - 1.0f;
-            h[4 * k + 1] = (((static_cast<float>(i >> 6) + u01(4 * k + 1)) / 64.0f) * 2.0f - 1.0f) * (2.0f / 3.0f);
+            h[4 * k + 1] = (((static_cast<float>(i >> 6) + u01(4 * k + 1)) / 64.0f) * 2.0f - 1.0f) * cam->frameMaxSy;
             h[4 * k + 2] = u01(4 * k + 2);
             h[4 * k + 3] = u01(4 * k + 3);
         }
@@ -844,9 +871,25 @@ zoic_status zoic_camera_set_precision(zoic_camera *cam, zoic_precision mode)
     return ZOIC_OK;
 }
 
+zoic_status zoic_camera_set_frame_aspect(zoic_camera *cam, float max_abs_sy)
+{
+    if (!cam || !(max_abs_sy > 0.0f) || !std::isfinite(max_abs_sy)) return fail(ZOIC_ERR_INVALID_ARGUMENT, "max_abs_sy must be a positive number");
+    if (max_abs_sy != cam->frameMaxSy) {   // other probes: the samples are laid out again and the verdict taken again at the next update
+        cam->frameMaxSy = max_abs_sy;
+        cam->fastProbeReady = false;
+        cam->fastVerdictValid = false;
+    }
+    return ZOIC_OK;
+}
+
 zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed)
 {
     if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
+    if (cam->device != ZOIC_DEVICE_NONE && seed != cam->seed) {   // the resident kernel holds the tables -- the seed of a tile's per-ray streams among them -- by value
+        DeviceGuard guard(cam->device);
+        ZOIC_HIP(guard.error());
+        ZOIC_HIP(cam->mail.stop());
+    }
     cam->seed = seed;
     cam->kolb.seed = seed;
     cam->thin.seed = seed;
@@ -1123,29 +1166,39 @@ zoic_status zoic_create_rays_arnold(zoic_camera *cam, uint64_t n, const zoic_cam
     return status;
 }
 
-// the resident per-sample kernel is running (or has just been started); see mailbox.hip
-static zoic_status mailbox_ensure_running(zoic_camera *cam, unsigned slot)
+}  // extern "C"
+
+// the resident kernel is running (or has just been started), watching `slot` and -- wantWorkers -- with its tile workers; see mailbox.hip
+static zoic_status mailbox_ensure_running(zoic_camera *cam, unsigned slot, bool wantWorkers)
 {
     Mailbox &M = cam->mail;
     std::lock_guard<std::mutex> lk(M.launchM);
     ZOIC_HIP(M.init());
     volatile MailHeader *h = M.header();
-    if (slot + 1 > M.slotsInUse.load(std::memory_order_relaxed)) {
-        // a tid beyond the slots the resident launch watches: it retires (stop flag) and starts again watching more
+    const bool moreSlots = slot + 1 > M.slotsInUse.load(std::memory_order_relaxed);
+    const bool moreWorkers = wantWorkers && M.workerGroups.load(std::memory_order_relaxed) == 0u;
+    if (moreSlots || moreWorkers) {
+        // a tid beyond the slots the resident launch watches, or the camera's first tile: it retires (stop flag; tiles in flight are
+        // finished first) and starts again watching more / with the worker waves
         if (h->alive != 0u) {
             M.request(0)->stop = 1u;
             std::atomic_thread_fence(std::memory_order_seq_cst);
             ZOIC_HIP(hipStreamSynchronize(M.stream));
             M.request(0)->stop = 0u; h->alive = 0u;
         }
-        h->slotsInUse = slot + 1;
-        M.slotsInUse.store(slot + 1, std::memory_order_release);
+        if (moreSlots) { h->slotsInUse = slot + 1; M.slotsInUse.store(slot + 1, std::memory_order_release); }
+        if (moreWorkers) {
+            uint32_t groups = kTileWorkerGroups;
+            if (const char *env = std::getenv("ZOIC_TILE_WORKER_GROUPS")) { const long v = std::atol(env); if (v >= 1 && v <= 1024) groups = static_cast<uint32_t>(v); }
+            h->workerGroups = groups;
+            M.workerGroups.store(groups, std::memory_order_release);
+        }
     }
     if (h->alive != 0u) {
         // alive is cleared by the kernel's last store; a kernel that died without it leaves the stream idle (or in error)
         const hipError_t q = hipStreamQuery(M.stream);
         if (q == hipErrorNotReady) { (void)hipGetLastError(); return ZOIC_OK; }
-        if (q != hipSuccess) return fail(ZOIC_ERR_HIP, std::string("per-sample kernel: ") + hipGetErrorString(q));
+        if (q != hipSuccess) return fail(ZOIC_ERR_HIP, std::string("resident kernel: ") + hipGetErrorString(q));
     }
     ZOIC_HIP(hipStreamSynchronize(M.stream));   // the previous resident kernel has retired (its last store is long done)
     const int model = cam->params.p.lensModel;
@@ -1153,13 +1206,48 @@ static zoic_status mailbox_ensure_running(zoic_camera *cam, unsigned slot)
     M.request(0)->stop = 0u;
     h->alive = 1u;
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    char *d = static_cast<char *>(M.mem.dev);
-    const int rc = launch_mailbox(cam->kolb, cam->thin, cam->bokehDev, model, mode, reinterpret_cast<MailHeader *>(d),
-                                  reinterpret_cast<const MailRequest *>(d + 64), reinterpret_cast<MailReply *>(d + 64 + 64 * kMailSlots), M.dServed,
-                                  M.dServed + kMailSlots, cam->dCounters, M.stream);
-    if (rc != 0) { h->alive = 0u; return fail(ZOIC_ERR_HIP, std::string("per-sample kernel launch: ") + hipGetErrorString(static_cast<hipError_t>(rc))); }
+    const int rc = launch_mailbox(cam->kolb, cam->thin, cam->bokehDev, model, mode, M.mem.dev, M.dState, cam->dCounters,
+                                  M.workerGroups.load(std::memory_order_relaxed), M.stream);
+    if (rc != 0) { h->alive = 0u; return fail(ZOIC_ERR_HIP, std::string("resident kernel launch: ") + hipGetErrorString(static_cast<hipError_t>(rc))); }
     return ZOIC_OK;
 }
+
+// Spin until `ready()`; the resident kernel may retire (idle / lifetime) around a call and is started again from here.
+template <class Ready>
+static zoic_status mailbox_await(zoic_camera *cam, unsigned slot, bool wantWorkers, Ready ready)
+{
+    Mailbox &M = cam->mail;
+    std::chrono::steady_clock::time_point t0;
+    for (uint64_t spins = 1;; ++spins) {
+        if (ready()) return ZOIC_OK;
+        __builtin_ia32_pause();
+        if ((spins & 2047u) != 0u) continue;
+        if (M.header()->alive == 0u) {   // the kernel retired (idle / lifetime) around this call: start it again
+            if (zoic_status s = mailbox_ensure_running(cam, slot, wantWorkers)) return s;
+        } else if ((spins & 0xfffffu) == 0u) {
+            // every ~20 ms: a kernel that died (fault) never clears `alive` -- ask the stream; and never wait for ever (20 s)
+            if (zoic_status s = mailbox_ensure_running(cam, slot, wantWorkers)) return s;
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0x100000u) t0 = now;
+            else if (now - t0 > std::chrono::seconds(20)) return fail(ZOIC_ERR_HIP, "resident kernel did not answer");
+        }
+    }
+}
+
+// the tile in flight on `slot` (if any) has been answered; slotM[slot] is held
+static zoic_status tile_settle_locked(zoic_camera *cam, unsigned slot)
+{
+    Mailbox &M = cam->mail;
+    const uint32_t seq = M.tileSeq[slot];
+    if (seq == 0u) return ZOIC_OK;
+    volatile MailTileDone *dn = M.tile_done(slot);
+    if (zoic_status s = mailbox_await(cam, slot, true, [&] { return dn->seq == seq; })) return s;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    M.tileSeq[slot] = 0u;
+    return ZOIC_OK;
+}
+
+extern "C" {
 
 zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *input, zoic_camera_output *output, uint16_t tid)
 {
@@ -1182,29 +1270,19 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
     const unsigned slot = tid % kMailSlots;
     std::lock_guard<std::mutex> slotLock(M.slotM[slot]);
     if (M.slotsInUse.load(std::memory_order_acquire) <= slot || M.header()->alive == 0u)
-        if (zoic_status s = mailbox_ensure_running(cam, slot)) return s;
+        if (zoic_status s = mailbox_ensure_running(cam, slot, false)) return s;
+    if (zoic_status s = tile_settle_locked(cam, slot)) return s;   // a tile submitted on this slot and not waited for yet comes first
     // request: data words first, the sequence number last in every 16-byte chunk (x86 stores stay in program order)
     const uint32_t seq = ++M.seq[slot];
     volatile MailRequest *q = M.request(slot);
-    q->rngZ = rng.z; q->rngW = rng.w; q->pad2 = 0u;
+    q->rngZ = rng.z; q->rngW = rng.w; q->kind = 0u;
     q->lensy = input->lensy; q->rngX = rng.x; q->rngY = rng.y;
     q->sx = input->sx; q->sy = input->sy; q->lensx = input->lensx;
     std::atomic_thread_fence(std::memory_order_release);
     q->seq2 = seq; q->seq1 = seq; q->seq0 = seq;
     // reply: complete when its three chunks carry this call's number
     volatile MailReply *a = M.reply(slot);
-    for (uint64_t spins = 1;; ++spins) {
-        if (a->seq0 == seq && a->seq1 == seq && a->seq2 == seq) break;
-        __builtin_ia32_pause();
-        if ((spins & 2047u) != 0u) continue;
-        if (M.header()->alive == 0u) {   // the kernel retired (idle / lifetime) around this call: start it again
-            if (zoic_status s = mailbox_ensure_running(cam, slot)) return s;
-        } else if ((spins & 0xfffffu) == 0u) {
-            // every ~20 ms: a kernel that died (fault) never clears `alive` -- ask the stream; and never wait for ever
-            if (zoic_status s = mailbox_ensure_running(cam, slot)) return s;
-            if (spins > (1ull << 30)) return fail(ZOIC_ERR_HIP, "per-sample kernel did not answer");
-        }
-    }
+    if (zoic_status s = mailbox_await(cam, slot, false, [&] { return a->seq0 == seq && a->seq1 == seq && a->seq2 == seq; })) return s;
     std::atomic_thread_fence(std::memory_order_acquire);
     zoic_ray r;
     r.ox = a->ox; r.oy = a->oy; r.oz = a->oz; r.dx = a->dx; r.dy = a->dy; r.dz = a->dz; r.weight = a->weight; r.flags = a->flags;
@@ -1212,6 +1290,170 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
     const uint32_t tries = (r.flags >> 1) & 31u;
     for (uint32_t i = 0; i < 2u * tries; ++i) (void)xor128(rng);
     expand_record(r, *output);
+    return ZOIC_OK;
+}
+
+// ---- tiles (include/zoic_amd.h): bucket-sized batches through the resident kernel, no launch ------------------------------------
+static zoic_status tile_alloc(zoic_camera *cam, uint32_t capacity, uint16_t tid, zoic_tile **out)
+{
+    std::unique_ptr<zoic_tile> t(new zoic_tile());
+    t->cam = cam; t->tid = tid; t->slot = tid % kMailSlots; t->capacity = capacity;
+    const size_t inBytes = (static_cast<size_t>(capacity) * sizeof(zoic_camera_input) + 63u) & ~static_cast<size_t>(63u);
+    const hipError_t e = t->mem.reserve(inBytes + static_cast<size_t>(capacity) * sizeof(zoic_camera_output));
+    if (e != hipSuccess) return fail(ZOIC_ERR_HIP, std::string("tile buffers: ") + hipGetErrorString(e));
+    t->inputs = static_cast<zoic_camera_input *>(t->mem.host);
+    t->outputs = reinterpret_cast<zoic_camera_output *>(static_cast<char *>(t->mem.host) + inBytes);
+    t->dIn = reinterpret_cast<uint64_t>(t->mem.dev);
+    t->dOut = t->dIn + inBytes;
+    *out = t.release();
+    return ZOIC_OK;
+}
+
+// post n rows at (dIn -> dOut) on `slot`; slotM[slot] is held and no tile is in flight on it
+static zoic_status tile_post_locked(zoic_camera *cam, unsigned slot, uint32_t n, uint64_t dIn, uint64_t dOut, uint64_t base, uint32_t *seqOut)
+{
+    Mailbox &M = cam->mail;
+    if (M.slotsInUse.load(std::memory_order_acquire) <= slot || M.workerGroups.load(std::memory_order_acquire) == 0u || M.header()->alive == 0u)
+        if (zoic_status s = mailbox_ensure_running(cam, slot, true)) return s;
+    const uint32_t seq = ++M.seq[slot];
+    volatile MailTileRequest *q = reinterpret_cast<volatile MailTileRequest *>(M.request(slot));
+    q->baseHi = static_cast<uint32_t>(base >> 32); q->pad = 0u; q->kind = 1u;
+    q->outLo = static_cast<uint32_t>(dOut); q->outHi = static_cast<uint32_t>(dOut >> 32); q->baseLo = static_cast<uint32_t>(base);
+    q->inLo = static_cast<uint32_t>(dIn); q->inHi = static_cast<uint32_t>(dIn >> 32); q->n = n;
+    std::atomic_thread_fence(std::memory_order_release);   // the caller's input rows and the words above, then the numbers
+    q->seq2 = seq; q->seq1 = seq; q->seq0 = seq;
+    M.tileSeq[slot] = seq;
+    *seqOut = seq;
+    return ZOIC_OK;
+}
+
+static zoic_status check_tile_call(const zoic_camera *cam)
+{
+    if (zoic_status s = check_ray_call(cam)) return s;
+    const int model = cam->params.p.lensModel;
+    if (model != ZOIC_RAYTRACED && model != ZOIC_THINLENS)
+        return fail(ZOIC_ERR_INVALID_ARGUMENT, "lensModel NONE produces no rays (zoic.cpp:1966-1968)");
+    return ZOIC_OK;
+}
+
+zoic_status zoic_tile_create(zoic_camera *cam, uint32_t capacity, uint16_t tid, zoic_tile **out)
+{
+    if (!out) return fail(ZOIC_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
+    if (cam->device == ZOIC_DEVICE_NONE) return fail(ZOIC_ERR_NO_DEVICE, "tables-only camera: rays need a gfx950 device (no CPU path)");
+    if (capacity == 0u || capacity > kTileMaxSamples) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile capacity must be 1 ... ZOIC_TILE_MAX_SAMPLES");
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    return tile_alloc(cam, capacity, tid, out);
+}
+
+void zoic_tile_destroy(zoic_tile *tile)
+{
+    if (!tile) return;
+    (void)zoic_tile_wait(tile);   // the GPU may still be writing into the arrays freed below
+    DeviceGuard guard(tile->cam->device);
+    tile->mem.release();
+    delete tile;
+}
+
+zoic_camera_input *zoic_tile_inputs(zoic_tile *tile) { return tile ? tile->inputs : nullptr; }
+zoic_camera_output *zoic_tile_outputs(zoic_tile *tile) { return tile ? tile->outputs : nullptr; }
+uint32_t zoic_tile_capacity(const zoic_tile *tile) { return tile ? tile->capacity : 0u; }
+
+zoic_status zoic_tile_submit(zoic_tile *tile, uint32_t n, uint64_t ray_index_base)
+{
+    if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
+    zoic_camera *cam = tile->cam;
+    if (zoic_status s = check_tile_call(cam)) return s;
+    if (n > tile->capacity) return fail(ZOIC_ERR_INVALID_ARGUMENT, "n exceeds the tile's capacity");
+    if (n == 0u) return ZOIC_OK;
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    std::lock_guard<std::mutex> slotLock(cam->mail.slotM[tile->slot]);
+    // one request per slot at a time: this tile's previous submit, or another tile of the same slot (tids 64 apart), comes first
+    if (cam->mail.mem.host) if (zoic_status s = tile_settle_locked(cam, tile->slot)) return s;
+    tile->seq = 0u;
+    return tile_post_locked(cam, tile->slot, n, tile->dIn, tile->dOut, ray_index_base, &tile->seq);
+}
+
+zoic_status zoic_tile_wait(zoic_tile *tile)
+{
+    if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
+    zoic_camera *cam = tile->cam;
+    if (tile->seq == 0u) return ZOIC_OK;
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    std::lock_guard<std::mutex> slotLock(cam->mail.slotM[tile->slot]);
+    // (a later call on the slot may have settled it already: then tileSeq has moved on and the rows are complete)
+    if (cam->mail.tileSeq[tile->slot] == tile->seq) if (zoic_status s = tile_settle_locked(cam, tile->slot)) return s;
+    tile->seq = 0u;
+    return ZOIC_OK;
+}
+
+int zoic_tile_done(zoic_tile *tile)
+{
+    if (!tile || tile->seq == 0u) return 1;
+    zoic_camera *cam = tile->cam;
+    std::lock_guard<std::mutex> slotLock(cam->mail.slotM[tile->slot]);
+    if (cam->mail.tileSeq[tile->slot] != tile->seq) return 1;
+    return cam->mail.tile_done(tile->slot)->seq == tile->seq ? 1 : 0;
+}
+
+zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,
+                                         uint64_t ray_index_base, uint16_t tid)
+{
+    if (zoic_status s = check_tile_call(cam)) return s;
+    if (n == 0u) return ZOIC_OK;
+    if (!inputs || !outputs) return fail(ZOIC_ERR_INVALID_ARGUMENT, "NULL argument");
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    Mailbox &M = cam->mail;
+    const unsigned slot = tid % kMailSlots;
+    // Page-locked, mapped caller arrays (zoic_host_alloc / zoic_host_register) are read and written in place; anything else goes
+    // through the slot's own page-locked staging, 16 Ki rows at a time on two buffers, so that the copy-in of piece k+1 and the
+    // copy-out of piece k-1 run beside the GPU's work on piece k.
+    uint64_t dIn = 0, dOut = 0;
+    {
+        hipPointerAttribute_t ai, ao;
+        const bool pinned = hipPointerGetAttributes(&ai, inputs) == hipSuccess && ai.type == hipMemoryTypeHost && ai.devicePointer &&
+                            hipPointerGetAttributes(&ao, outputs) == hipSuccess && ao.type == hipMemoryTypeHost && ao.devicePointer;
+        (void)hipGetLastError();   // "not a registered pointer" is an answer, not an error of this call
+        if (pinned) { dIn = reinterpret_cast<uint64_t>(ai.devicePointer); dOut = reinterpret_cast<uint64_t>(ao.devicePointer); }
+    }
+    std::lock_guard<std::mutex> slotLock(M.slotM[slot]);
+    if (M.mem.host) if (zoic_status s = tile_settle_locked(cam, slot)) return s;
+    uint32_t seq = 0;
+    if (dIn != 0 && dOut != 0) {
+        for (uint32_t off = 0; off < n; off += kTileMaxSamples) {
+            const uint32_t m = std::min<uint32_t>(kTileMaxSamples, n - off);
+            if (zoic_status s = tile_post_locked(cam, slot, m, dIn + static_cast<uint64_t>(off) * sizeof(zoic_camera_input),
+                                                 dOut + static_cast<uint64_t>(off) * sizeof(zoic_camera_output), ray_index_base + off, &seq)) return s;
+            if (zoic_status s = tile_settle_locked(cam, slot)) return s;
+        }
+        return ZOIC_OK;
+    }
+    constexpr uint32_t kPiece = 16384;
+    const uint32_t piece = std::min<uint32_t>(n, kPiece);
+    const unsigned buffers = n > kPiece ? 2u : 1u;
+    for (unsigned b = 0; b < buffers; ++b) {
+        zoic_tile *&t = M.ownTile[slot][b];
+        if (t && t->capacity < piece) { t->mem.release(); delete t; t = nullptr; }
+        if (!t) { uint32_t cap = 1024; while (cap < piece) cap <<= 1; if (zoic_status s = tile_alloc(cam, cap, tid, &t)) return s; }
+    }
+    uint32_t prevOff = 0, prevM = 0;
+    unsigned k = 0;
+    for (uint32_t off = 0; off < n; off += piece, ++k) {
+        const uint32_t m = std::min<uint32_t>(piece, n - off);
+        zoic_tile *t = M.ownTile[slot][k & 1u];
+        std::memcpy(t->inputs, inputs + off, static_cast<size_t>(m) * sizeof(zoic_camera_input));   // beside the GPU's work on piece k-1
+        if (zoic_status s = tile_settle_locked(cam, slot)) return s;                                  // piece k-1 is complete
+        if (zoic_status s = tile_post_locked(cam, slot, m, t->dIn, t->dOut, ray_index_base + off, &seq)) return s;
+        if (prevM) std::memcpy(outputs + prevOff, M.ownTile[slot][(k - 1u) & 1u]->outputs, static_cast<size_t>(prevM) * sizeof(zoic_camera_output));
+        prevOff = off; prevM = m;
+    }
+    if (zoic_status s = tile_settle_locked(cam, slot)) return s;
+    std::memcpy(outputs + prevOff, M.ownTile[slot][(k - 1u) & 1u]->outputs, static_cast<size_t>(prevM) * sizeof(zoic_camera_output));
     return ZOIC_OK;
 }
 

@@ -33,6 +33,7 @@ namespace {
 constexpr uint64_t kTile = 256;                      // rays per workgroup tile: slabs and chunks are aligned to it
 constexpr uint64_t kMinChunkPayloadBytes = 64ull << 20;   // chunks of at least 64 MB of payload
 constexpr unsigned kChunksPerSlab = 4;
+constexpr uint64_t kMaxChunksPerSlab = 64;
 
 #define FRAME_HIP(expr)                                                                                      \
     do {                                                                                                     \
@@ -53,10 +54,16 @@ struct Lane {
     int device = 0;
     zoic_camera *cam = nullptr;
     hipStream_t compute[2] = {nullptr, nullptr}, copy = nullptr;
-    hipEvent_t streamDone[3] = {nullptr, nullptr, nullptr};   // the tail of compute[0], compute[1], copy for the call in flight
+    // the tails of compute[0], compute[1], copy as the LAST render_* call left them.  Every render_* call starts by making all
+    // three streams wait for all three (order_behind_previous): the staging buffers (records / payload) and the chunk events are
+    // shared by consecutive calls whatever their n, chunk size, sample pointers or root stream -- two calls never overlap on a lane
+    hipEvent_t streamDone[3] = {nullptr, nullptr, nullptr};
+    bool doneRecorded[3] = {false, false, false};
     hipEvent_t samplesReady = nullptr;                        // zoic_frame_generate_samples' kernel
-    std::vector<hipEvent_t> computed, copied;                 // per chunk: trace (+ pack) done / peer copy done
-    std::vector<bool> copiedRecorded;                         // copied[k] has been recorded at least once
+    std::vector<hipEvent_t> computed;                         // per chunk: trace (+ pack) done
+    // what the last render_device call did on this lane (zoic_frame_get_lane_info)
+    int peerToRoot = 0, rootToPeer = 0;                       // hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess both succeeded
+    uint64_t lastRays = 0, lastBytesToRoot = 0; uint32_t lastChunks = 0;
     DeviceBuffer<float> samples;                              // generated samples of this lane's slab
     uint64_t samplesN = 0, samplesBase = 0; bool haveSamples = false;
     DeviceBuffer<zoic_ray> records;                           // this lane's slab, 32 B/ray
@@ -81,19 +88,29 @@ uint64_t chunk_rays_for(const zoic_frame *f, uint64_t slabRays, int bytesPerRay)
         c = std::max<uint64_t>(c, kMinChunkPayloadBytes / static_cast<uint64_t>(bytesPerRay));
     }
     c = std::max<uint64_t>(kTile, c / kTile * kTile);
-    return c;
+    // at most kMaxChunksPerSlab chunks (an event, a launch and a peer copy each): a tiny zoic_frame_set_chunk_rays on a large
+    // slab is raised to what gives that many
+    const uint64_t floorRays = ((slabRays + kMaxChunksPerSlab - 1) / kMaxChunksPerSlab + kTile - 1) / kTile * kTile;
+    return std::max(c, floorRays);
 }
 
 zoic_status ensure_chunk_events(Lane &L, size_t chunks)
 {
     while (L.computed.size() < chunks) {
-        hipEvent_t a = nullptr, b = nullptr;
+        hipEvent_t a = nullptr;
         FRAME_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
         L.computed.push_back(a);
-        FRAME_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        L.copied.push_back(b);
-        L.copiedRecorded.push_back(false);
     }
+    return ZOIC_OK;
+}
+
+// Every stream of the lane behind everything the previous render_* call queued on ANY of them (device side; the current device
+// is the lane's).  A wait on an event of the same stream is free.
+zoic_status order_behind_previous(Lane &L)
+{
+    for (hipStream_t s : {L.compute[0], L.compute[1], L.copy})
+        for (int t = 0; t < 3; ++t)
+            if (L.doneRecorded[t]) FRAME_HIP(hipStreamWaitEvent(s, L.streamDone[t], 0));
     return ZOIC_OK;
 }
 
@@ -155,13 +172,15 @@ zoic_status zoic_frame_create(const int *devices, int n_devices, zoic_frame **ou
         if (e == hipSuccess && i > 0 && L.device != devices[0]) {
             // direct xGMI copies root <-> peer; "already enabled" (another frame of this process) is fine, "not supported"
             // leaves hipMemcpyPeerAsync to stage through the host -- slower, still correct
+            // (zoic_frame_get_lane_info reports which of the two it was: a gather that crawls is then explained, not guessed at)
+            const auto enabled = [](hipError_t r) { return r == hipSuccess || r == hipErrorPeerAccessAlreadyEnabled; };
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, L.device, devices[0]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[0], 0);
+            if (hipDeviceCanAccessPeer(&can, L.device, devices[0]) == hipSuccess && can) L.peerToRoot = enabled(hipDeviceEnablePeerAccess(devices[0], 0)) ? 1 : 0;
             (void)hipGetLastError();
             DeviceGuard rootGuard(devices[0]);
-            if (hipDeviceCanAccessPeer(&can, devices[0], L.device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(L.device, 0);
+            if (hipDeviceCanAccessPeer(&can, devices[0], L.device) == hipSuccess && can) L.rootToPeer = enabled(hipDeviceEnablePeerAccess(L.device, 0)) ? 1 : 0;
             (void)hipGetLastError();
-        }
+        } else { L.peerToRoot = L.rootToPeer = 1; }   // the root itself, or the root's device listed again: no link involved
         if (e != hipSuccess) st = fail_status(ZOIC_ERR_HIP, std::string("frame streams: ") + hipGetErrorString(e));
     }
     if (st != ZOIC_OK) {
@@ -184,7 +203,6 @@ void zoic_frame_destroy(zoic_frame *frame)
             for (hipEvent_t &e : L.streamDone) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             if (L.samplesReady) (void)hipEventDestroy(L.samplesReady);
             for (hipEvent_t e : L.computed) (void)hipEventDestroy(e);
-            for (hipEvent_t e : L.copied) (void)hipEventDestroy(e);
             L.samples.release(); L.records.release(); L.payload.release();
             if (&L == &frame->lanes[0] && frame->rootStart) (void)hipEventDestroy(frame->rootStart);
         }
@@ -279,13 +297,24 @@ zoic_status zoic_frame_generate_samples(zoic_frame *frame, uint64_t n, uint64_t 
     return ZOIC_OK;
 }
 
-zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, void *d_out,
-                                     zoic_frame_layout layout, void *root_stream)
+}  // extern "C"
+
+namespace {
+
+// A render call that fails half-way has traces and peer copies of earlier lanes / chunks in flight into the caller's buffer and
+// the current lane's tails not yet joined to the root stream: the public entry points wait for all of it (the error path may
+// block) before they hand the status back, so that a caller who frees or reuses d_out after a failure races with nothing.
+zoic_status settle_after_failure(zoic_frame *frame, zoic_status st)
 {
-    if (!frame) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "frame is NULL");
-    if (layout != ZOIC_FRAME_RECORDS && layout != ZOIC_FRAME_PAYLOAD) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "bad layout");
-    if (n == 0) return ZOIC_OK;
-    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15u)) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "d_out must be non-NULL and 16-byte aligned");
+    const std::string why = zoic_last_error_string();
+    (void)zoic_frame_synchronize(frame);
+    for (Lane &L : frame->lanes) for (bool &r : L.doneRecorded) r = false;   // everything has drained: nothing left to order behind
+    return fail_status(st, why);
+}
+
+zoic_status render_device_impl(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, void *d_out,
+                               zoic_frame_layout layout, void *root_stream)
+{
     const int nd = static_cast<int>(frame->lanes.size());
     const bool payload = layout == ZOIC_FRAME_PAYLOAD;
     const int rowBytes = payload ? 28 : 32;
@@ -308,6 +337,8 @@ zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float 
         FRAME_HIP(guard.error());
         const bool root = i == 0;
         const uint64_t slab = hi - lo;
+        if (zoic_status s = order_behind_previous(L)) return s;
+        L.lastRays = slab; L.lastBytesToRoot = 0; L.lastChunks = 0;
         // the root's slab is ONE launch (nothing to overlap it with: sub-launches cost 8-13 % on one GPU)
         const uint64_t chunk = root ? slab : chunk_rays_for(frame, slab, rowBytes);
         const size_t chunks = static_cast<size_t>((slab + chunk - 1) / chunk);
@@ -334,8 +365,6 @@ zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float 
                 FRAME_HIP(hipStreamWaitEvent(cs, frame->rootStart, 0));
                 if (!d_samples) FRAME_HIP(hipStreamWaitEvent(cs, L.samplesReady, 0));
             }
-            // this chunk's staging (records / payload rows) is free once its previous peer copy has left
-            if (!root && L.copiedRecorded[k]) FRAME_HIP(hipStreamWaitEvent(cs, L.copied[k], 0));
             zoic_ray *dst = records + (a - lo);
             if (zoic_status s = zoic_create_rays_device(L.cam, m, samples + (a - lo) * 4, nullptr, ray_index_base + a, dst, cs)) return s;
             if (payload) {
@@ -352,15 +381,16 @@ zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float 
                 const size_t bytes = static_cast<size_t>(m) * static_cast<size_t>(rowBytes);
                 if (L.device == R.device) FRAME_HIP(hipMemcpyAsync(to, src, bytes, hipMemcpyDeviceToDevice, L.copy));
                 else FRAME_HIP(hipMemcpyPeerAsync(to, R.device, src, L.device, bytes, L.copy));
-                FRAME_HIP(hipEventRecord(L.copied[k], L.copy));
-                L.copiedRecorded[k] = true;
+                L.lastBytesToRoot += bytes;
             }
         }
         // the caller's root stream continues behind everything this lane queued
         hipStream_t tails[3] = {L.compute[0], L.compute[1], L.copy};
+        L.lastChunks = static_cast<uint32_t>(chunks);
         for (int t = 0; t < 3; ++t) {
             if (!used[t]) continue;
             FRAME_HIP(hipEventRecord(L.streamDone[t], tails[t]));
+            L.doneRecorded[t] = true;
             DeviceGuard rootGuard(R.device);
             FRAME_HIP(rootGuard.error());
             FRAME_HIP(hipStreamWaitEvent(rootStream, L.streamDone[t], 0));
@@ -369,10 +399,8 @@ zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float 
     return ZOIC_OK;
 }
 
-zoic_status zoic_frame_render_local(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, zoic_ray *const *d_rays)
+zoic_status render_local_impl(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, zoic_ray *const *d_rays)
 {
-    if (!frame) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "frame is NULL");
-    if (n == 0) return ZOIC_OK;
     const int nd = static_cast<int>(frame->lanes.size());
     for (int i = 0; i < nd; ++i) {
         Lane &L = frame->lanes[static_cast<size_t>(i)];
@@ -390,12 +418,49 @@ zoic_status zoic_frame_render_local(zoic_frame *frame, uint64_t n, const float *
                 FRAME_HIP(L.records.reserve(hi - lo));
             }
             dst = L.records.ptr;
-            // an earlier gather may still be copying out of this buffer
-            for (size_t k = 0; k < L.copied.size(); ++k) if (L.copiedRecorded[k]) FRAME_HIP(hipStreamWaitEvent(L.compute[0], L.copied[k], 0));
         }
+        // behind whatever the previous call left on ANY stream of the lane: an earlier gather may still be copying out of the
+        // records, an earlier render_device may still be tracing into them on compute[1]
+        if (zoic_status s = order_behind_previous(L)) return s;
         if (!d_samples) FRAME_HIP(hipStreamWaitEvent(L.compute[0], L.samplesReady, 0));
         if (zoic_status s = zoic_create_rays_device(L.cam, hi - lo, samples, nullptr, ray_index_base + lo, dst, L.compute[0])) return s;
+        FRAME_HIP(hipEventRecord(L.streamDone[0], L.compute[0]));
+        L.doneRecorded[0] = true;
     }
+    return ZOIC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, void *d_out,
+                                     zoic_frame_layout layout, void *root_stream)
+{
+    if (!frame) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "frame is NULL");
+    if (layout != ZOIC_FRAME_RECORDS && layout != ZOIC_FRAME_PAYLOAD) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "bad layout");
+    if (n == 0) return ZOIC_OK;
+    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15u)) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "d_out must be non-NULL and 16-byte aligned");
+    if (zoic_status s = render_device_impl(frame, n, d_samples, ray_index_base, d_out, layout, root_stream)) return settle_after_failure(frame, s);
+    return ZOIC_OK;
+}
+
+zoic_status zoic_frame_render_local(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, zoic_ray *const *d_rays)
+{
+    if (!frame) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "frame is NULL");
+    if (n == 0) return ZOIC_OK;
+    if (zoic_status s = render_local_impl(frame, n, d_samples, ray_index_base, d_rays)) return settle_after_failure(frame, s);
+    return ZOIC_OK;
+}
+
+zoic_status zoic_frame_get_lane_info(const zoic_frame *frame, int i, zoic_frame_lane_info *out)
+{
+    if (!frame || !out || i < 0 || static_cast<size_t>(i) >= frame->lanes.size()) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "bad lane");
+    const Lane &L = frame->lanes[static_cast<size_t>(i)];
+    std::memset(out, 0, sizeof(*out));
+    out->device = L.device;
+    out->peer_access_to_root = L.peerToRoot; out->peer_access_from_root = L.rootToPeer;
+    out->rays = L.lastRays; out->bytes_to_root = L.lastBytesToRoot; out->chunks = L.lastChunks;
     return ZOIC_OK;
 }
 

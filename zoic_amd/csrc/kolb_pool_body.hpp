@@ -204,6 +204,12 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #ifndef ZOIC_POOL_SLIM
 #define ZOIC_POOL_SLIM 0   // 1: 40-byte entries: the exit-pupil scale / translation are looked up again when a ray is popped
 #endif
+#ifndef ZOIC_STORE_TRANSPOSED
+#define ZOIC_STORE_TRANSPOSED 0   // 1: a fresh batch's records leave through an LDS transpose (two contiguous-KB stores per wave)
+#endif
+#if ZOIC_STORE_TRANSPOSED && ZOIC_POOL_SLIM
+#error "ZOIC_STORE_TRANSPOSED stages in the upper half of pool1's float4 array: not with ZOIC_POOL_SLIM"
+#endif
 #ifndef ZOIC_SEARCH_DRAWS
 #define ZOIC_SEARCH_DRAWS 2   // lens draws the retry search of the IMAGE kernels samples per round (one wait for all their records); measured on C3: 1 -> 38.8, 2 -> 41.1, 3 -> 40.4, 4 -> 39.6 Grays/s
 #endif
@@ -566,11 +572,31 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             }
 #endif
         }
-        if (finished) {
+        {
             float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;
             if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
-            store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
-                             (tries > 0 ? 1u : 0u) | (tries << 1) | ((lutMiss & 1u) << 6));
+            const uint32_t flags = (tries > 0 ? 1u : 0u) | (tries << 1) | ((lutMiss & 1u) << 6);
+#if ZOIC_STORE_TRANSPOSED
+            // Phase A holds 64 CONSECUTIVE rays in lane order and most of them finish here: their records are one contiguous 2 KB
+            // block.  store_ray_record writes it as 2 x 64 half-sectors at a 32-byte stride per instruction; transposed through LDS --
+            // the upper halves of pool0 / pool1 are free during a fresh batch (poolCnt < 64 and the push comes after this) -- each of
+            // the two store instructions writes one contiguous KB (lane j: 16-byte piece j, then 64 + j), with the lanes of unfinished
+            // rays masked off.  Phase B's rays are scattered: they keep the per-lane store.
+            if (!fromPool) {
+                float4 *stA = pool0 + 64, *stB = reinterpret_cast<float4 *>(pool1) + 64;
+                stA[lane] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);   // zoic.cpp:1960-1961
+                stB[lane] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, flags));
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long fin = __ballot(finished);
+                const float4 *half = (lane & 1u) ? stB : stA;
+                float4 *dst = reinterpret_cast<float4 *>(out + (idx - lane));   // idx = batch base + lane (advance_batches has moved base1 on)
+                const float4 p0 = half[lane >> 1], p1 = half[32u + (lane >> 1)];
+                if ((fin >> (lane >> 1)) & 1ull) dst[lane] = p0;
+                if ((fin >> (32u + (lane >> 1))) & 1ull) dst[64u + lane] = p1;
+                __builtin_amdgcn_wave_barrier();
+            } else
+#endif
+            if (finished) store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);   // zoic.cpp:1960-1961
         }
         ZOIC_MARK(7)   // finish: counters + record store
         if constexpr (GUARD) {

@@ -1,28 +1,42 @@
-// mailbox.hip -- camera_create_ray(node, input, output, tid) (zoic.cpp:1752) at CALL latency: a persistent one-wave
-// kernel per camera that render threads talk to through mapped, page-locked host memory.
+// mailbox.hip -- camera_create_ray(node, input, output, tid) (zoic.cpp:1752) at CALL latency, one sample or one TILE at a time:
+// a resident kernel per camera that render threads talk to through mapped, page-locked host memory.
 //
 // Why.  Arnold calls camera_create_ray once per camera sample from every render thread and waits for the ray.  Answering a
-// call with a kernel launch + stream synchronise costs 28-33 us (round 2) -- 30x slower than the CPU plug-in it replaces,
-// whatever the kernel does.  Here nothing is launched per call:
-//   * slot w (= tid mod 64) of the mailbox is owned by wave w of the resident launch (64 waves).  A render thread writes its sample and
-//     its retry-stream state into the slot's REQUEST (three 16-byte chunks, each carrying the call's sequence number in
-//     its first word, written last) and spins on the slot's REPLY;
-//   * the wave polls its request with three global_load_dwordx4 across PCIe (host memory is mapped uncached on the GPU:
-//     every poll sees memory); when the three chunks carry one NEW sequence number it evaluates the ray -- the reference's own loop, one ray per lane, STRICT or FAST arithmetic (optics.hpp /
-//     fast_optics.hpp; a FAST ray with a decision inside a guard band is re-evaluated on the spot by the listed kernel's rule, kolb_listed_body.hpp) -- bumps the
-//     camera's counters and writes the REPLY: three 16-byte chunks, sequence number last.  A chunk is one PCIe
-//     transaction: torn reads are impossible within a chunk and detected across chunks (all three numbers must agree), so
-//     no fences or doorbells are needed in either direction;
+// call with a kernel launch + stream synchronise costs 28-33 us per sample (round 2) and 52-76 us per batch call whatever the
+// batch carries (round 4): a bucket of 64 x 64 pixels served by launches runs 30-80x below what the kernels do.  Here nothing is
+// launched per call:
+//   * SLOT waves.  Slot w (= tid mod 64) of the mailbox is owned by wave w of the resident launch.  A render thread writes its
+//     request into the slot's 64-byte REQUEST line (three 16-byte chunks, each ending in the call's sequence number, written last)
+//     and spins on the answer.  The wave polls the line with ONE load across PCIe (lanes 0-3 fetch its four chunks; host memory
+//     is mapped uncached on the GPU: every poll sees memory); when the three chunks carry one NEW sequence number the request is
+//     complete.  A chunk is one PCIe transaction: torn reads are impossible within a chunk and detected across chunks, so no
+//     fences or doorbells are needed in either direction;
+//   * ONE SAMPLE (kind 0): the slot's wave evaluates the ray with one lane -- the reference's own loop, STRICT or FAST arithmetic
+//     (optics.hpp / fast_optics.hpp; a FAST ray with a decision inside a guard band is re-evaluated on the spot by the listed
+//     kernel's rule, kolb_listed_body.hpp) -- and writes the REPLY line: three 16-byte chunks, sequence number last;
+//   * A TILE (kind 1: n <= 65536 AtCameraInput rows in mapped host memory -> n AtCameraOutput rows in mapped host memory): the
+//     slot's wave POSTS the tile as a job in device memory -- descriptor, a ticket counter (generation << 32 | next batch), a bit
+//     in the launch's 64-bit work mask -- and the WORKER waves of the launch (kTileWorkerGroups x 4, started with the first tile a
+//     camera sees) take 64-sample batches off it with one atomicAdd each, the slot's wave among them.  A batch is evaluated at
+//     FULL LANE WIDTH by the same device functions as a single sample (one ray per lane; ray i draws its retries from the stream
+//     keyed by base + i exactly as the batch kernels do, so a tile equals zoic_create_rays_arnold bit for bit): the 28-byte input
+//     rows arrive as 7 coalesced dword loads per lane across PCIe and are transposed through LDS, the 84-byte output rows leave
+//     as 21 coalesced dword stores per lane.  Every wave releases its rows at system scope before it counts its batch done; the
+//     wave that counts the last one writes the slot's TILE-DONE line.  No launch, no stream, no synchronise: a 4096-sample tile
+//     is answered in ~15 us where a launch-based call took 76;
 //   * the kernel retires by itself after 1 ms without a call and after 50 ms in any case (a resident kernel would stall the
 //     application's hipDeviceSynchronize / hipFree for ever); the next call finds `alive == 0` and launches it again
-//     (~20 us, once).  node_update / node_finish / the counter getters stop it first.
+//     (~20 us, once).  node_update / node_finish / the counter getters stop it first.  A wave never leaves with a batch in hand,
+//     and a slot's wave hands out every batch of its own tile before it looks at its exit flag.
 // Results are those of the batch kernels for RAYTRACED, bit for bit in STRICT and in FAST: every Kolb kernel of the library
 // evaluates a ray with the same device functions, the FAST arithmetic is written with explicit FMAs (fast_optics.hpp: the branchy
 // trace here and the unrolled trace of the batch kernels round alike) and a ray too close to call follows the listed kernel's rule
-// (tests/test_boundary_gpu.py: a fresh tid's first call == the one-ray batch launch on the same stream).  THINLENS is evaluated in the reference's arithmetic (thin_ray_strict) in EVERY precision mode -- one lane has
-// nothing to gain from the fast variant -- so under ZOIC_PRECISION_FAST with optical vignetting on, where the batch path runs
-// thin_refill.hip's fast arithmetic, a per-sample ray and a batch ray of the same sample can differ in low-order bits (never in
-// a decision: the fast vignetting test is decision-safe).  include/zoic_amd.h states this at zoic_camera_create_ray.
+// (tests/test_boundary_gpu.py: a fresh tid's first call == the one-ray batch launch on the same stream; tests/test_tile_gpu.py: a
+// tile == zoic_create_rays_arnold).  THINLENS: a single sample is evaluated in the reference's arithmetic (thin_ray_strict) in EVERY
+// precision mode -- one lane has nothing to gain from the fast variant -- so under ZOIC_PRECISION_FAST with optical vignetting on,
+// where the batch path runs thin_refill.hip's fast arithmetic, a per-sample ray and a batch ray of the same sample can differ in
+// low-order bits (never in a decision: the fast vignetting test is decision-safe); a TILE takes the batch path's arithmetic
+// (thin_vignet_try<true>) and equals it.  include/zoic_amd.h states this at zoic_camera_create_ray.
 #include "kolb_listed_body.hpp"   // listed_one_ray; kolb_pool_body.hpp: setup_ray, retry_direction (+ kolb_device.hpp: lens_sample, the traces, zoicDynLds)
 #include "mailbox.hpp"
 #include "thin_device.hpp"
@@ -94,14 +108,35 @@ __device__ __forceinline__ OneRay kolb_one_ray(const KolbTable &T, const BokehTa
     return r;
 }
 
+// system scope (mapped host memory: never from / into a GPU cache) and agent scope (the job table: coherent across the XCDs' L2s)
+// (the addresses arrive as integers: say "global" so that these are global_load / global_store, not flat_*)
+typedef uint32_t __attribute__((address_space(1))) GlobalWord;
+__device__ __forceinline__ uint32_t load_sys(const uint32_t *p) { return __hip_atomic_load((const GlobalWord *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_sys(uint32_t *p, uint32_t v) { __hip_atomic_store((GlobalWord *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <class V> __device__ __forceinline__ V load_dev(const V *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class V> __device__ __forceinline__ void store_dev(V *p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t first_lane(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+__device__ __forceinline__ unsigned long long first_lane64(unsigned long long v)
+{
+    return (static_cast<unsigned long long>(first_lane(static_cast<uint32_t>(v >> 32))) << 32) | first_lane(static_cast<uint32_t>(v));
+}
+__device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have landed before any lane reads another lane's words
+{
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr uint32_t kTileStageWords = 512;   // per wave: 64 x 7 input dwords, then 64 x 8 record dwords
+
 // model: ZOIC_THINLENS 0 / ZOIC_RAYTRACED 1 (zoic_amd.h); mode: 0 STRICT, 1 FAST decision-safe, 2 FAST unchecked.
-// 4 workgroups x 16 waves: wave w of the launch owns slot w and works with ONE lane -- a render thread never waits for
-// another thread's ray (one wave for all slots measured 8 us per call with one calling thread, 29 us with four).
-// control (device memory): [0] exit flag (set by wave 0: stop request / 1 ms without a call / 50 ms of life),
-// [1] waves that have left, [2..3] wall-clock time of the last call any wave answered.
+// Waves 0 .. 63 of the launch are the SLOT waves (wave w owns slot w: a render thread never waits for another thread's ray --
+// one wave for all slots measured 8 us per call with one calling thread, 29 us with four), the waves behind them the tile WORKERS.
+// st->control (device memory): [0] exit flag (set by wave 0: stop request / 1 ms without a call / 50 ms of life), [1] waves that
+// have left, [2..3] wall-clock time of the last call any wave answered, [4..5] the work mask.
 __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, const ThinTable Th, const BokehTables B, int model, int mode,
-                                                             MailHeader *header, const MailRequest *requests, MailReply *replies,
-                                                             uint32_t *served, uint32_t *control, DeviceCounters *counters, uint32_t ldsWords)
+                                                             char *mapped, MailDeviceState *st, DeviceCounters *counters, uint32_t ldsWords,
+                                                             uint32_t totalWaves)
 {
     if (threadIdx.x < kLutEntries) {
         zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
@@ -115,59 +150,182 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.x * (kMailBlock / 64u) + (threadIdx.x >> 6);
+    const uint32_t waveId = blockIdx.x * (kMailBlock / 64u) + (threadIdx.x >> 6);
+    const bool slotRole = waveId < kMailSlots;
+    const uint32_t slot = slotRole ? waveId : 0u;
+    float *stage = zoicDynLds + kLutLdsWords + ldsWords + (threadIdx.x >> 6) * kTileStageWords;
+    MailHeader *header = reinterpret_cast<MailHeader *>(mapped);
+    const MailRequest *requests = reinterpret_cast<const MailRequest *>(mapped + kMailRequestsOffset);
+    MailReply *replies = reinterpret_cast<MailReply *>(mapped + kMailRepliesOffset);
+    MailTileDone *tileDone = reinterpret_cast<MailTileDone *>(mapped + kMailTileDoneOffset);
+    uint32_t *control = st->control;
+    unsigned long long *workMask = reinterpret_cast<unsigned long long *>(control + 4);
     volatile unsigned long long *lastCall = reinterpret_cast<volatile unsigned long long *>(control + 2);
-    // All control flow below is wave-uniform (the polled words are broadcast to SGPRs); lane 0 evaluates the ray.
-    uint32_t mine = served[slot];                      // sequence number of the last call this slot answered
+    // All control flow below is wave-uniform (the polled words are broadcast to SGPRs).
+    uint32_t mine = slotRole ? st->served[slot] : 0u;   // sequence number of the last call this slot answered
     const unsigned long long start = wall_clock64();   // 100 MHz
-    if (slot == 0 && lane == 0) *lastCall = start;
-    uint32_t succ = 0, vign = 0, tir = 0;
+    if (waveId == 0 && lane == 0) *lastCall = start;
+    uint32_t succ = 0, vign = 0, tir = 0;               // per lane; summed when the wave retires
     // slots no render thread has used yet are not watched at all: their waves leave at once (the host starts the launch again
     // when a new tid shows up -- 63 waves reading host memory for nothing slowed every poll of the busy ones down)
-    bool watched;
-    {
+    bool watched = true;
+    if (slotRole) {
         u32x4 line, ctl;
         poll_uncached(reinterpret_cast<const uint4 *>(header), control, line, ctl);
         watched = slot < lane_word(line.z, 0);
     }
     const uint4 *myChunk = reinterpret_cast<const uint4 *>(requests + slot) + (lane < 3u ? lane : 3u);
+    bool ownJob = false;        // slot role: this slot's tile still has batches to hand out
+    uint32_t idlePolls = 0;     // worker role
     while (watched) {
-        u32x4 line, ctl;   // ctl: the launch's control block = {exit flag, waves out, time of the last call (lo, hi)}
-        poll_uncached(myChunk, control, line, ctl);
-        // chunk k of the request sits in lane k: {sx, sy, lensx, seq} {lensy, rng.x, rng.y, seq} {rng.z, rng.w, -, seq} {stop (slot 0), ...}
-        const uint32_t seq = lane_word(line.w, 0);
-        const bool work = seq != mine && seq == lane_word(line.w, 1) && seq == lane_word(line.w, 2);
-        const uint32_t stop = lane_word(line.x, 3);
-        const uint32_t leave = lane_word(ctl.x, 0);
-        const unsigned long long lastSeen = (static_cast<unsigned long long>(lane_word(ctl.w, 0)) << 32) | lane_word(ctl.z, 0);
-        const unsigned long long now = wall_clock64();
-        if (work) {
-            if (lane == 0) {
-                *lastCall = now;
-                const float4 s = make_float4(__builtin_bit_cast(float, lane_word(line.x, 0)), __builtin_bit_cast(float, lane_word(line.y, 0)),
-                                             __builtin_bit_cast(float, lane_word(line.z, 0)), __builtin_bit_cast(float, lane_word(line.x, 1)));
-                const Rng rng{lane_word(line.y, 1), lane_word(line.z, 1), lane_word(line.x, 2), lane_word(line.y, 2)};
-                V3 o, d; float w; uint32_t tries, lutMiss = 0;
-                if (model == 0) {   // THINLENS, zoic.cpp:1771-1846 (reference arithmetic in every precision mode)
-                    Rng q = rng;
-                    const ThinRay r = thin_ray_strict(Th, B, bokehLds, s, q, [] {});
-                    o = r.origin; d = r.dir; w = r.w; tries = r.tries;
-                    if (Th.useDof) { if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ; }
-                } else {
-                    OneRay r;
-                    if (mode == 0) r = kolb_one_ray<true>(T, B, lutLds, bokehLds, s, rng, false);
-                    else {
-                        r = kolb_one_ray<false>(T, B, lutLds, bokehLds, s, rng, mode == 1);
-                        if (r.unsure) {   // a decision too close to call: the ray is evaluated as the batch path's listed kernel does it
-                            const ListedRay q = listed_one_ray(T, B, lutLds, bokehLds, s, rng);   // (kolb_listed_body.hpp: same rule, same bits)
-                            r.o = q.o; r.d = q.d; r.w = q.w; r.tries = q.tries; r.lutMiss = q.lutMiss; r.tir = q.tir;
-                        }
-                    }
-                    o = V3{r.o.x * -1.0f, r.o.y * -1.0f, r.o.z * -1.0f}; d = V3{r.d.x * -1.0f, r.d.y * -1.0f, r.d.z * -1.0f};   // zoic.cpp:1960-1961
-                    w = r.w; tries = r.tries; lutMiss = r.lutMiss; tir += r.tir;
-                    if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ;
+        if (wall_clock64() - start > kMailHardLifeTicks) break;   // safety net (never seen): the host reports a tile that is never answered
+        uint32_t work = 0;      // 1: one sample (slot role), 2: one 64-sample batch of a tile
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        Rng rng{1u, 2u, 3u, 4u};
+        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobBatches = 0, jobSeq = 0;
+        unsigned long long jobIn = 0, jobOut = 0, jobBase = 0;
+        if (slotRole && !ownJob) {
+            u32x4 line, ctl;   // ctl: the launch's control block = {exit flag, waves out, time of the last call (lo, hi)}
+            poll_uncached(myChunk, control, line, ctl);
+            // chunk k of the request sits in lane k: {sx, sy, lensx, seq} {lensy, rng.x, rng.y, seq} {rng.z, rng.w, kind, seq} {stop (slot 0), ...}
+            seq = lane_word(line.w, 0);
+            const bool fresh = seq != mine && seq == lane_word(line.w, 1) && seq == lane_word(line.w, 2);
+            const uint32_t stop = lane_word(line.x, 3);
+            const uint32_t leave = lane_word(ctl.x, 0);
+            const unsigned long long lastSeen = (static_cast<unsigned long long>(lane_word(ctl.w, 0)) << 32) | lane_word(ctl.z, 0);
+            const unsigned long long now = wall_clock64();
+            if (!fresh) {
+                if (slot == 0 && (stop != 0u || (now > lastSeen && now - lastSeen > kMailIdleTicks) || now - start > kMailLifeTicks)) {
+                    if (lane == 0) __hip_atomic_store(control, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // everybody out
+                    break;
                 }
-                const uint32_t flags = (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6);
+                if (leave != 0u) break;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            if (lane == 0) *lastCall = now;
+            if (lane_word(line.z, 2) == 0u) {   // ---- one sample
+                work = 1;
+                s = make_float4(__builtin_bit_cast(float, lane_word(line.x, 0)), __builtin_bit_cast(float, lane_word(line.y, 0)),
+                                __builtin_bit_cast(float, lane_word(line.z, 0)), __builtin_bit_cast(float, lane_word(line.x, 1)));
+                rng = Rng{lane_word(line.y, 1), lane_word(line.z, 1), lane_word(line.x, 2), lane_word(line.y, 2)};
+            } else {                            // ---- a tile: {inLo, inHi, n, seq} {outLo, outHi, baseLo, seq} {baseHi, -, kind, seq}
+                const uint32_t n = lane_word(line.z, 0);
+                const uint32_t batches = (n + 63u) >> 6;
+                if (lane == 0) {
+                    TileJob *J = st->jobs + slot;
+                    store_dev(&J->in, (static_cast<unsigned long long>(lane_word(line.y, 0)) << 32) | lane_word(line.x, 0));
+                    store_dev(&J->out, (static_cast<unsigned long long>(lane_word(line.y, 1)) << 32) | lane_word(line.x, 1));
+                    store_dev(&J->base, (static_cast<unsigned long long>(lane_word(line.x, 2)) << 32) | lane_word(line.z, 1));
+                    store_dev(&J->n, n); store_dev(&J->batches, batches); store_dev(&J->seq, seq);
+                    store_dev(&st->tickets[slot].done, 0u);
+                    // descriptor before ticket: whoever draws a ticket of generation `seq` reads this descriptor.  The ticket
+                    // and the mask bit need no order between them (a worker that sees the bit first draws a stale ticket and comes back)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    store_dev(&st->tickets[slot].next, static_cast<unsigned long long>(seq) << 32);
+                    if (batches != 0u) (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else store_uncached(reinterpret_cast<uint4 *>(tileDone + slot), make_uint4(0u, 0u, 0u, seq));   // an empty tile is done
+                }
+                mine = seq;
+                ownJob = batches != 0u;
+                continue;
+            }
+        }
+        if (work == 0u) {   // ---- draw a batch: a slot's wave from its own tile, a worker from any slot with its bit set
+            if (slotRole) jobSlot = slot;
+            else {
+                const unsigned long long mask = first_lane64(load_dev(workMask));
+                if (mask == 0ull) {
+                    if ((++idlePolls & 3u) == 0u && first_lane(load_dev(control)) != 0u) break;   // exit flag: only with nothing left to hand out
+                    if (idlePolls < 64u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);   // ~0.2 us while tiles keep coming, ~0.9 us when they do not
+                    continue;
+                }
+                idlePolls = 0;
+                const uint32_t r = waveId & 63u;   // every worker starts its search at another slot
+                const unsigned long long rot = r ? ((mask >> r) | (mask << (64u - r))) : mask;
+                jobSlot = (static_cast<uint32_t>(__builtin_ctzll(rot)) + r) & 63u;
+            }
+            unsigned long long t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(&st->tickets[jobSlot].next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = first_lane64(t);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const TileJob *J = st->jobs + jobSlot;
+            jobSeq = first_lane(load_dev(&J->seq));
+            jobBatches = first_lane(load_dev(&J->batches));
+            batch = static_cast<uint32_t>(t);
+            if (jobSeq != static_cast<uint32_t>(t >> 32) || batch >= jobBatches) {   // a ticket of a tile that has been handed out already
+                if (slotRole) ownJob = false; else __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            // the LAST valid ticket clears the slot's bit: the tile cannot complete (and the slot post another) before this wave is done
+            if (batch + 1u == jobBatches && lane == 0) (void)__hip_atomic_fetch_and(workMask, ~(1ull << jobSlot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            jobN = first_lane(load_dev(&J->n));
+            jobIn = first_lane64(load_dev(&J->in)); jobOut = first_lane64(load_dev(&J->out)); jobBase = first_lane64(load_dev(&J->base));
+            work = 2;
+        }
+
+        // ---- the pass's samples: the slot's one sample in lane 0, or 64 consecutive rows of the tile --------------------------
+        bool active = lane == 0;
+        uint32_t first = 0, cnt = 1;
+        unsigned long long rayIndex = 0;
+        if (work == 2u) {
+            first = batch * 64u;
+            cnt = jobN - first < 64u ? jobN - first : 64u;
+            // AtCameraInput rows are 7 dwords (sx sy dsx dsy lensx lensy relative_time): lane l fetches dword k * 64 + l of the batch's
+            // 7 * cnt -- whole 256-byte runs per instruction across PCIe -- and picks its row out of LDS
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(jobIn) + static_cast<size_t>(first) * 7u;
+            const uint32_t total = cnt * 7u;
+            uint32_t w7[7];
+#pragma unroll
+            for (uint32_t k = 0; k < 7u; ++k) { const uint32_t j = k * 64u + lane; w7[k] = load_sys(src + (j < total ? j : total - 1u)); }
+#pragma unroll
+            for (uint32_t k = 0; k < 7u; ++k) stage[k * 64u + lane] = __builtin_bit_cast(float, w7[k]);
+            wave_lds_fence();
+            active = lane < cnt;
+            const uint32_t row = (active ? lane : 0u) * 7u;
+            s = make_float4(stage[row], stage[row + 1u], stage[row + 4u], stage[row + 5u]);
+            wave_lds_fence();   // ... before the records go into the same words
+            rayIndex = jobBase + first + lane;
+        }
+
+        // ---- the rays (ONE site for both kinds of work: the reference's loop, one ray per lane) ---------------------------------
+        V3 o{0.0f, 0.0f, 0.0f}, d{0.0f, 0.0f, 0.0f};
+        float w = 0.0f;
+        uint32_t tries = 0, lutMiss = 0;
+        if (active) {
+            if (model == 0) {   // THINLENS, zoic.cpp:1771-1846
+                ThinRay r;
+                if (work == 2u) {   // a tile's ray = the batch kernels' ray: its own stream, seeded at its first redraw; FAST where they run FAST
+                    Rng q{1u, 2u, 3u, 4u};
+                    if (mode != 0 && Th.useDof && Th.ovDistance > 0.0f) r = thin_ray_fast_vignet(Th, B, bokehLds, s, q, [&] { q = rng_for_ray(Th.seed, rayIndex); });
+                    else r = thin_ray_strict(Th, B, bokehLds, s, q, [&] { q = rng_for_ray(Th.seed, rayIndex); });
+                } else {            // one sample: the calling tid's stream, the reference's arithmetic in every precision mode
+                    Rng q = rng;
+                    r = thin_ray_strict(Th, B, bokehLds, s, q, [] {});
+                }
+                o = r.origin; d = r.dir; w = r.w; tries = r.tries;
+                if (Th.useDof) { if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ; }
+            } else {
+                if (work == 2u) rng = rng_for_ray(T.seed, rayIndex);
+                OneRay r;
+                if (mode == 0) r = kolb_one_ray<true>(T, B, lutLds, bokehLds, s, rng, false);
+                else {
+                    r = kolb_one_ray<false>(T, B, lutLds, bokehLds, s, rng, mode == 1);
+                    if (r.unsure) {   // a decision too close to call: the ray is evaluated as the batch path's listed kernel does it
+                        const ListedRay q = listed_one_ray(T, B, lutLds, bokehLds, s, rng);   // (kolb_listed_body.hpp: same rule, same bits)
+                        r.o = q.o; r.d = q.d; r.w = q.w; r.tries = q.tries; r.lutMiss = q.lutMiss; r.tir = q.tir;
+                    }
+                }
+                o = V3{r.o.x * -1.0f, r.o.y * -1.0f, r.o.z * -1.0f}; d = V3{r.d.x * -1.0f, r.d.y * -1.0f, r.d.z * -1.0f};   // zoic.cpp:1960-1961
+                w = r.w; tries = r.tries; lutMiss = r.lutMiss; tir += r.tir;
+                if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ;
+            }
+        }
+        const uint32_t flags = (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6);
+
+        // ---- the answer -----------------------------------------------------------------------------------------------------------
+        if (work == 1u) {
+            if (lane == 0) {
                 uint4 *a = reinterpret_cast<uint4 *>(replies + slot);
                 store_uncached(a, make_uint4(__builtin_bit_cast(uint32_t, o.x), __builtin_bit_cast(uint32_t, o.y), __builtin_bit_cast(uint32_t, o.z), seq));
                 store_uncached(a + 1, make_uint4(__builtin_bit_cast(uint32_t, d.x), __builtin_bit_cast(uint32_t, d.y), __builtin_bit_cast(uint32_t, d.z), seq));
@@ -176,15 +334,47 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             mine = seq;
             continue;
         }
-        if (slot == 0 && (stop != 0u || (now > lastSeen && now - lastSeen > kMailIdleTicks) || now - start > kMailLifeTicks)) {
-            if (lane == 0) __hip_atomic_store(control, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // everybody out
-            break;
+        // AtCameraOutput rows (84 bytes = 21 floats: origin, dir, dOdx, dOdy, dDdx, dDdy, weight[3]) as zoic_create_rays_arnold
+        // writes them (kernels.hip expand_outputs_kernel): origin / dir, dOdy = origin and dDdy = dir for retried rays
+        // (zoic.cpp:1974-1977), weight r = g = b, zeros in what camera_create_ray leaves alone.  One lane per output FLOAT.
+        {
+            float4 *rec = reinterpret_cast<float4 *>(stage) + 2u * lane;
+            rec[0] = make_float4(o.x, o.y, o.z, d.x);
+            rec[1] = make_float4(d.y, d.z, w, __builtin_bit_cast(float, flags));
+            wave_lds_fence();
+            uint32_t *dst = reinterpret_cast<uint32_t *>(jobOut) + static_cast<size_t>(first) * 21u;
+            const uint32_t total = cnt * 21u;
+#pragma unroll
+            for (uint32_t k = 0; k < 21u; ++k) {
+                const uint32_t j = k * 64u + lane;
+                if (j < total) {
+                    const uint32_t ray = j / 21u, f = j - ray * 21u;
+                    const float *r = stage + ray * 8u;
+                    const bool retried = (__builtin_bit_cast(uint32_t, r[7]) & 1u) != 0u;
+                    float v = 0.0f;                                  // dOdx (6-8), dDdx (12-14); dOdy / dDdy of first-try rays
+                    if (f < 6u) v = r[f];                            // origin, dir
+                    else if (f >= 18u) v = r[6];                     // weight r = g = b (the caller's initial weight is 1)
+                    else if (retried && f >= 9u && f < 12u) v = r[f - 9u];    // dOdy = origin
+                    else if (retried && f >= 15u) v = r[f - 12u];             // dDdy = dir
+                    store_sys(dst + j, __builtin_bit_cast(uint32_t, v));
+                }
+            }
+            wave_lds_fence();
         }
-        if (leave != 0u) break;
-        __builtin_amdgcn_s_sleep(8);
+        // this wave's rows are visible to the host before its batch counts as done; the wave that counts the tile's last batch has
+        // seen every other wave's count (and, through it, their releases) and reports the tile
+        __threadfence_system();
+        uint32_t before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(&st->tickets[jobSlot].done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        before = first_lane(before);
+        if (before + 1u == jobBatches) {
+            __threadfence_system();
+            if (lane == 0) store_uncached(reinterpret_cast<uint4 *>(tileDone + jobSlot), make_uint4(jobN, jobBatches, 0u, jobSeq));
+        }
     }
+    for (int off = 32; off > 0; off >>= 1) { succ += __shfl_xor(succ, off, 64); vign += __shfl_xor(vign, off, 64); tir += __shfl_xor(tir, off, 64); }
     if (lane == 0) {
-        served[slot] = mine;
+        if (slotRole) st->served[slot] = mine;
         // the counters of node_finish (zoic.cpp:1729-1732): one atomic per counter for the whole stay
         if (counters) {
             DeviceCounters *cs = counter_set(counters);
@@ -193,7 +383,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             if (tir) atomicAdd(&cs->tir, static_cast<unsigned long long>(tir));
         }
         __threadfence_system();
-        if (atomicAdd(control + 1, 1u) == kMailSlots - 1u) {   // the last wave out resets the control block and clears `alive`
+        if (atomicAdd(control + 1, 1u) == totalWaves - 1u) {   // the last wave out resets the control block and clears `alive`
             control[1] = 0u;
             __hip_atomic_store(control, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
@@ -204,15 +394,15 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
 
 }  // namespace
 
-int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, MailHeader *d_header,
-                   const MailRequest *d_requests, MailReply *d_replies, uint32_t *d_served, uint32_t *d_control, DeviceCounters *d_counters,
-                   void *stream)
+int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, void *d_mapped,
+                   MailDeviceState *d_state, DeviceCounters *d_counters, uint32_t workerGroups, void *stream)
 {
     const bool image = (model == 0 ? thin.useImage : kolb.useImage) != 0;
     const uint32_t ldsWords = (image && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
-    hipLaunchKernelGGL(mailbox_kernel, dim3(kMailSlots * 64u / kMailBlock), dim3(kMailBlock), (kLutLdsWords + ldsWords) * sizeof(float),
-                       static_cast<hipStream_t>(stream), kolb, thin, bokeh, model, mode, d_header, d_requests, d_replies, d_served, d_control,
-                       d_counters, ldsWords);
+    const uint32_t groups = kMailSlotGroups + workerGroups;
+    hipLaunchKernelGGL(mailbox_kernel, dim3(groups), dim3(kMailBlock), (kLutLdsWords + ldsWords + (kMailBlock / 64u) * kTileStageWords) * sizeof(float),
+                       static_cast<hipStream_t>(stream), kolb, thin, bokeh, model, mode, static_cast<char *>(d_mapped), d_state, d_counters, ldsWords,
+                       groups * (kMailBlock / 64u));
     return static_cast<int>(hipGetLastError());
 }
 

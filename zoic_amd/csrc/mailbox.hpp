@@ -1,4 +1,5 @@
-// mailbox.hpp -- the memory layout the per-sample mailbox kernel (mailbox.hip) and the host (capi.cpp) share.
+// mailbox.hpp -- the memory layout the resident kernel (mailbox.hip) and the host (capi.cpp) share: per-sample calls
+// (zoic_camera_create_ray) and TILE requests (zoic_tile_submit / zoic_camera_create_rays_tile) of one camera.
 #pragma once
 #include <cstdint>
 
@@ -6,18 +7,31 @@
 
 namespace zoic {
 
-constexpr uint32_t kMailSlots = 64;                       // one slot per wave of the resident launch; tid -> slot tid % 64
-constexpr uint32_t kMailBlock = 1024;                     // 16 waves per workgroup, 4 workgroups
+constexpr uint32_t kMailSlots = 64;                       // one slot per SLOT wave of the resident launch; tid -> slot tid % 64
+constexpr uint32_t kMailBlock = 256;                      // 4 waves per workgroup: 16 slot workgroups, then the tile workers'
+constexpr uint32_t kMailSlotGroups = kMailSlots * 64u / kMailBlock;
+constexpr uint32_t kTileWorkerGroups = 64;                // default number of worker workgroups (x 4 waves) once a tile has been submitted
+constexpr uint32_t kTileMaxSamples = 65536;               // samples per tile request (ZOIC_TILE_MAX_SAMPLES)
 constexpr unsigned long long kMailIdleTicks = 100000;     // 1 ms of the 100 MHz wall clock without a call: the kernel retires
 constexpr unsigned long long kMailLifeTicks = 5000000;    // 50 ms: ... and in any case, so that a device-wide synchronise ends
+constexpr unsigned long long kMailHardLifeTicks = 100000000;   // 1 s: no wave of a launch outlives this whatever it is waiting for (a safety net: never seen)
 
-// Every 16-byte chunk is written and read as ONE PCIe transaction and starts with the call's sequence number, written last
+// Every 16-byte chunk is written and read as ONE PCIe transaction and ends with the call's sequence number, written last
 // by the host: a chunk whose number is new carries new data, and a message is complete when its three numbers agree.
+// kind (the third chunk's third word): 0 = one sample, 1 = a tile.
 struct alignas(64) MailRequest {              // the number is the LAST word of every chunk
     float sx, sy, lensx; uint32_t seq0;       // AtCameraInput fields zoic reads (zoic.cpp:1853-1854, 1870)
     float lensy; uint32_t rngX, rngY, seq1;   // the calling tid's xorshift128 retry stream (zoic.cpp:647-652)
-    uint32_t rngZ, rngW, pad2, seq2;
+    uint32_t rngZ, rngW, kind, seq2;
     uint32_t stop, fill[3];                   // slot 0 only: the host asks the launch to retire (the wave polls ONE line)
+};
+// the same line carrying a tile: n AtCameraInput rows at `in` -> n AtCameraOutput rows at `out` (device addresses of mapped,
+// page-locked host memory), ray i drawing its retries from the stream keyed by base + i
+struct alignas(64) MailTileRequest {
+    uint32_t inLo, inHi, n, seq0;
+    uint32_t outLo, outHi, baseLo, seq1;
+    uint32_t baseHi, pad, kind, seq2;
+    uint32_t stop, fill[3];
 };
 struct alignas(64) MailReply {                // the number is the LAST word of a reply chunk: whatever order a chunk's bytes land in
     float ox, oy, oz; uint32_t seq0;          // output.origin
@@ -25,15 +39,42 @@ struct alignas(64) MailReply {                // the number is the LAST word of 
     float weight; uint32_t flags, pad2, seq2; // zoic_ray::weight / flags
     uint32_t fill[4];
 };
+// a tile's completion: ONE 16-byte chunk written by the wave that finished the tile's last batch, behind a system-scope release
+// of every wave's output rows
+struct alignas(64) MailTileDone {
+    uint32_t n, batches, pad, seq;
+    uint32_t fill[12];
+};
 struct alignas(64) MailHeader {
-    uint32_t pad0[2], slotsInUse, pad1;       // chunk 0: written by the host only, read once by every wave of a launch
-    uint32_t alive, pad2[3];                  // chunk 1: set by the host before a launch, cleared by the kernel as its last act
+    uint32_t pad0[2], slotsInUse, workerGroups;   // chunk 0: written by the host only, read once by every wave of a launch
+    uint32_t alive, pad2[3];                      // chunk 1: set by the host before a launch, cleared by the kernel as its last act
     uint32_t fill[8];
 };
-static_assert(sizeof(MailRequest) == 64 && sizeof(MailReply) == 64 && sizeof(MailHeader) == 64, "mailbox layout");
+static_assert(sizeof(MailRequest) == 64 && sizeof(MailTileRequest) == 64 && sizeof(MailReply) == 64 && sizeof(MailHeader) == 64 &&
+              sizeof(MailTileDone) == 64, "mailbox layout");
+// byte offsets into the mapped allocation
+constexpr size_t kMailRequestsOffset = 64, kMailRepliesOffset = kMailRequestsOffset + 64 * kMailSlots,
+                 kMailTileDoneOffset = kMailRepliesOffset + 64 * kMailSlots, kMailBytes = kMailTileDoneOffset + 64 * kMailSlots;
 
-int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, MailHeader *d_header,
-                   const MailRequest *d_requests, MailReply *d_replies, uint32_t *d_served, uint32_t *d_control, DeviceCounters *d_counters,
-                   void *stream);
+// Device-memory state of the resident launch (survives its retirements): what a slot has answered, the launch's control block,
+// and the tile jobs the slot waves post for the workers.
+struct alignas(64) TileJob {                  // written by the slot's wave, read by whoever holds a ticket of generation `seq`
+    unsigned long long in, out, base;
+    uint32_t n, batches, seq, pad[7];
+};
+struct alignas(64) TileTicket {               // (generation << 32) | next batch: one atomicAdd hands a batch out
+    unsigned long long next;
+    uint32_t done, pad[13];                   // batches finished (the wave that makes it `batches` reports the tile)
+};
+struct MailDeviceState {
+    uint32_t served[kMailSlots];              // sequence number of the last call each slot answered
+    alignas(64) uint32_t control[16];         // [0] exit flag, [1] waves that have left, [2..3] wall-clock time of the last call,
+                                              // [4..5] 64-bit mask of the slots whose tile still has batches to hand out
+    TileJob jobs[kMailSlots];
+    TileTicket tickets[kMailSlots];
+};
+
+int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, void *d_mapped,
+                   MailDeviceState *d_state, DeviceCounters *d_counters, uint32_t workerGroups, void *stream);
 
 }  // namespace zoic

@@ -15,6 +15,7 @@
 #include "kernels.hpp"
 #include "optics.hpp"
 #include "ray_store.hpp"
+#include "thin_device.hpp"
 #include "work_cursor.hpp"
 
 #pragma STDC FP_CONTRACT OFF
@@ -28,14 +29,6 @@ constexpr int kThinWaves = kThinBlock / 64;
 constexpr uint32_t kMinTrying = 16;   // the redraw loop goes on while at least this many lanes of the wave are redrawing
 
 extern __shared__ __align__(16) float thinRefillLds[];   // [bokeh row cell records (ldsWords)] [per wave: 128 pieces + 64 indices]
-
-// empericalOpticalVignetting, zoic.cpp:1297-1305
-__device__ __forceinline__ bool vignet_pass(const ThinTable &T, V3 origin, V3 dir)
-{
-    const V3 p{dir.x * T.ovDistance - origin.x, dir.y * T.ovDistance - origin.y, dir.z * T.ovDistance - origin.z};
-    const float hyp = sqrtf((p.x * p.x) + (p.y * p.y));
-    return fabsf(hyp) < T.apertureRadius * T.ovRadius;
-}
 
 // FAST (zoic_camera_set_precision): f32 rsq normalisation, the f32 disk mapping and v_sqrt in the vignetting test instead
 // of the reference's correctly rounded divides and square roots -- ~80 instead of ~140 instructions per redraw; direction
@@ -121,37 +114,8 @@ __global__ __launch_bounds__(kThinBlock) void thin_refill_kernel(const ThinTable
         bool trying = active;
         for (;;) {
             if (trying) {
-                V2 lens = useImage ? (rowCells ? bokeh_sample_cells<!FAST>(B, rowCells, T.bokehW, T.bokehH, u, v)
-                                               : bokeh_sample_device(B, T.bokehW, T.bokehH, u, v))
-                                   : (FAST ? concentric_disk_f32(u, v) : concentric_disk(u, v));
-                lens.x *= T.apertureRadius; lens.y *= T.apertureRadius;
-                V3 origin{lens.x, lens.y, 0.0f};
-                V3 dir;
-                bool clear;
-                if constexpr (FAST) {
-                    const V3 q{fpx - origin.x, fpy - origin.y, fpz - origin.z};
-                    const float inv = frsq_fast(q.x * q.x + q.y * q.y + q.z * q.z);
-                    dir = V3{q.x * inv, q.y * inv, q.z * inv};
-                    const float ax = dir.x * T.ovDistance, ay = dir.y * T.ovDistance;
-                    const float px = ax - origin.x, py = ay - origin.y;
-                    const float hyp = fsqrt_fast(px * px + py * py), lim = T.apertureRadius * T.ovRadius;
-                    clear = hyp < lim;
-                    // Decision-safe: the f32 shortcuts above are good to a few ulps of the terms of p; a test that close to the
-                    // limit is re-taken in the reference's arithmetic, lens sample included (rare and divergent -- except on
-                    // degenerate settings such as a vignetting distance of ~0 behind an image whose rim pixels sit ON the limit).
-                    if (fabsf(hyp - lim) <= 2.0e-6f * (fabsf(ax) + fabsf(ay) + fabsf(origin.x) + fabsf(origin.y))) {
-                        V2 ls = useImage ? (rowCells ? bokeh_sample_cells<true>(B, rowCells, T.bokehW, T.bokehH, u, v)
-                                                     : bokeh_sample_device(B, T.bokehW, T.bokehH, u, v))
-                                         : concentric_disk(u, v);
-                        ls.x *= T.apertureRadius; ls.y *= T.apertureRadius;
-                        origin = V3{ls.x, ls.y, 0.0f};
-                        dir = normalize3(V3{fpx - origin.x, fpy - origin.y, fpz - origin.z});
-                        clear = vignet_pass(T, origin, dir);
-                    }
-                } else {
-                    dir = normalize3(V3{fpx - origin.x, fpy - origin.y, fpz - origin.z});
-                    clear = vignet_pass(T, origin, dir);
-                }
+                V3 origin, dir;
+                const bool clear = thin_vignet_try<FAST>(T, B, rowCells, useImage, fpx, fpy, fpz, u, v, origin, dir);   // thin_device.hpp
                 const bool done = clear || tries > static_cast<uint32_t>(kMaxTries);
                 if (done) {
                     float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;      // zoic.cpp:1824-1830

@@ -144,6 +144,13 @@ class ZoicFrame:
     def synchronize(self):
         self._check(self._lib.zoic_frame_synchronize(self._h))
 
+    def lane_info(self, i):
+        """What device i's lane did in the last render() and how it reaches the root (zoic_frame_get_lane_info)."""
+        info = _capi.FrameLaneInfo()
+        self._check(self._lib.zoic_frame_get_lane_info(self._h, int(i), C.byref(info)))
+        return dict(device=info.device, peer_access_to_root=bool(info.peer_access_to_root), peer_access_from_root=bool(info.peer_access_from_root),
+                    chunks=info.chunks, rays=info.rays, bytes_to_root=info.bytes_to_root)
+
     def counters(self):
         c = _capi.Counters()
         self._check(self._lib.zoic_frame_get_counters(self._h, C.byref(c)))
