@@ -44,13 +44,13 @@ VALU_PEAK_ARCH_TWIPS = 1.2288   # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VAL
 CPU_SLAB_RAYS = 16_588_800       # the fixed slab (= config 2's full size) the CPU legs are quoted on
 
 NOTES = {
-    "roofline": "achieved = 44 B/ray (SURVEY 8d: 16 B sample + 28 B origin/dir/weight) x rays / kernel_ms; kernel_ms = the launch (main kernel + "
-                "the listed kernel over its work list) by HIP events on the launch stream; frac48 = the same with the 32 B record the kernels "
-                "really write; flop_frac = FLOP/ray counted by the oracle (profiles/flop_model_r04.json: 106 x interface visits + 130 x "
-                "tries) x rays/s over 157 TFLOP/s; traffic, lane_instr, lane_util = the committed rocprofv3 PMC run of this (config, "
-                "mode), profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE) -- null when the kernel sources have changed since "
-                "(csrc_sha16); valu_frac = wave64 VALU instr/s over 1024 SIMDs x 2.4 GHz / 2; the Kolb kernels are bound by VALU issue "
-                "(bound: valu), the thin lens (C1) by HBM",
+    "roofline": "two candidate bounds (SURVEY 8d): HBM at 44 B/ray (16 B sample + 28 B origin/dir/weight) and FP32 VALU at the FLOP/ray the "
+                "oracle counts (profiles/flop_model_r04.json: 106 x interface visits + 130 x tries) against 157 TFLOP/s; bound = the lower "
+                "ceiling in rays/s (ceilings_grays), achieved / peak / frac = binding_frac are ITS figures, the other bound's are hbm_gb_s / "
+                "hbm_frac / flop_frac; kernel_ms = the launch (main kernel + the listed kernel over its work list) by HIP events on the "
+                "launch stream; frac48 = HBM fraction with the 32 B record the kernels really write; traffic, lane_instr, lane_util = the "
+                "committed rocprofv3 PMC run of this (config, mode), profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE) -- null when "
+                "the kernel sources have changed since (csrc_sha16); valu_frac = wave64 VALU instr/s over 1024 SIMDs x 2.4 GHz / 2",
     "multi_gpu": "value = ONE headline frame per step in N ray-index slabs incl. the gather of the 28 B/ray payload on rank 0 (RCCL "
                  "batch_isend_irecv, chunks overlapped with the trace); root_ingest_frac = bytes into rank 0 per second over (N-1) x 153 "
                  "GB/s: a gather to ONE root is bounded by its links, 3.25 GB of a C3 frame >= 3.0 ms at 8 GPUs against 3.3 ms to render "
@@ -249,19 +249,33 @@ def flop_per_ray(cfg_name):
 
 
 def roofline_block(cfg_name, precision, n, kernel_ms, thin):
-    achieved = ALGO_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9
+    """two candidate bounds -- HBM at 44 B/ray and FP32 VALU at the oracle-counted FLOP/ray -- both reported, and the
+    block's achieved / peak / frac are those of the BINDING one (the lower ceiling in rays/s): the thin lens is bound by HBM, the
+    Kolb configs by VALU.  binding_frac == frac; the other bound's figures sit beside it (hbm_* / flop_*)."""
+    secs = kernel_ms * 1e-3
+    hbm_gbs = ALGO_BYTES_PER_RAY * n / secs / 1e9
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS
     ent = pmc_entry(cfg_name, precision)
-    roof = {"bound": "hbm" if thin else "valu", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(ent["hbm_bytes_per_launch"]) if ent else None, "kernel_ms": round(kernel_ms, 4), "bytes_per_ray": ALGO_BYTES_PER_RAY,
-            "frac48": round(RECORD_BYTES_PER_RAY * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "kernel": "thin_rays_kernel" if thin else {"fast": "kolb_pool_guard_kernel + kolb_listed_kernel", "unchecked": "kolb_pool_fast_kernel",
-                                                        "strict": "kolb_pool_strict_kernel"}[precision]}
     fl = None if thin else flop_per_ray(cfg_name)
+    tf = fl * n / secs / 1e12 if fl else None
+    flop_frac = tf / FP32_PEAK_TFLOPS if tf else None
+    ceil_hbm = HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_RAY / 1e9                      # Grays/s
+    ceil_valu = FP32_PEAK_TFLOPS * 1e12 / fl / 1e9 if fl else None
+    valu_binds = ceil_valu is not None and ceil_valu < ceil_hbm
+    if valu_binds:
+        roof = {"bound": "valu", "achieved": round(tf, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
+    roof.update(binding_frac=roof["frac"], ceilings_grays={"hbm": round(ceil_hbm, 1), "valu": round(ceil_valu, 1) if ceil_valu else None},
+                traffic=round(ent["hbm_bytes_per_launch"]) if ent else None, kernel_ms=round(kernel_ms, 4), bytes_per_ray=ALGO_BYTES_PER_RAY,
+                hbm_gb_s=round(hbm_gbs, 1), hbm_frac=round(hbm_frac, 4),
+                frac48=round(RECORD_BYTES_PER_RAY * n / secs / 1e9 / HBM_PEAK_GBS, 4),
+                kernel="thin_rays_kernel" if thin else {"fast": "kolb_pool_guard_kernel + kolb_listed_kernel", "unchecked": "kolb_pool_fast_kernel",
+                                                        "strict": "kolb_pool_strict_kernel"}[precision])
     if fl:
-        tf = fl * n / (kernel_ms * 1e-3) / 1e12
-        roof.update(flop_per_ray=round(fl), tflops=round(tf, 1), flop_frac=round(tf / FP32_PEAK_TFLOPS, 3))
+        roof.update(flop_per_ray=round(fl), tflops=round(tf, 1), flop_frac=round(flop_frac, 3))
     if ent and ent.get("lane_instr_per_ray") and not thin:
-        rate = ent["lane_instr_per_ray"] / 64.0 * n / (kernel_ms * 1e-3) / 1e12
+        rate = ent["lane_instr_per_ray"] / 64.0 * n / secs / 1e12
         roof.update(lane_instr=round(ent["lane_instr_per_ray"]), lane_util=round(ent.get("valu_thread_util", 0.0), 3),
                     valu_frac=round(rate / VALU_PEAK_ARCH_TWIPS, 3))
     if ent is None:
@@ -329,7 +343,7 @@ def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, par
     thin = cfg["params"]["lensModel"] == 0
     roof = roofline_block(cfg_name, precision, n, kernel_ms, thin)
     ent = {"config": cfg_name, "mode": precision, "rays": n, "steps": steps, "value": round(n * steps / elapsed / 1e6, 1),
-           "ms_per_step": round(elapsed / steps * 1e3, 4), "kernel_ms": roof["kernel_ms"], "hbm_frac": roof["frac"],
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "kernel_ms": roof["kernel_ms"], "hbm_frac": roof["hbm_frac"], "binding_frac": roof["frac"], "bound": roof["bound"],
            "zero_weight": frame_stats(counters, counters["succesRays"] + counters["vignettedRays"])}
     for k in ("traffic", "lane_instr", "lane_util", "valu_frac"):
         if roof.get(k) is not None:
@@ -672,20 +686,23 @@ def main():
                 line["single_process_frame"] = spf
             if sharded:
                 line["sharded_frame"] = sharded
-            if note:
-                line["multi_gpu_incomplete"] = note
             line["notes"] = {k: NOTES[k] for k in ("roofline", "multi_gpu", "mode")}
-            text = json.dumps(line, separators=(",", ":"))
+            out = dict(line)
+            if note:   # FIRST in the line: whoever reads only its head sees that the multi-GPU legs did not all finish
+                out = {"multi_gpu_incomplete": note}
+                out.update(line)
+            text = json.dumps(out, separators=(",", ":"))
             if len(text) > 6000:
-                del line["notes"]
-                text = json.dumps(line, separators=(",", ":"))
+                del out["notes"]
+                text = json.dumps(out, separators=(",", ":"))
             flush_c_stdio()
             print(text, flush=True)
 
         def give_up():
+            # the line with what HAS been measured, then a NON-ZERO exit: a hung gather must not look like a finished run
             if rank == 0:
                 finish_line("timed out after %d s behind the weak-scaling leg" % args.sharded_timeout)
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(args.sharded_timeout, give_up)
         watchdog.daemon = True
         watchdog.start()

@@ -31,3 +31,16 @@ def test_shim_calls_only_declared_entry_points():
     for name in ("sensorWidth", "sensorHeight", "focalLength", "fStop", "focalDistance", "useImage", "bokehPath", "lensModel",
                  "lensDataPath", "kolbSamplingLUT", "useDof", "opticalVignettingDistance", "opticalVignettingRadius", "exposureControl"):
         assert '"%s"' % name in src, name
+
+
+def test_tile_buffer_header_is_plain_cpp11_over_the_c_abi(tmp_path):
+    """arnold/zoic_tile_buffer.hpp (accumulate -> flush -> serve over zoic_tile_*) needs no SDK: it compiles on its own as C++11 and
+    calls only declared entry points (its GPU test is tests/test_tile_gpu.py::test_the_cpp_tile_buffer_accumulate_flush_serve)."""
+    src = tmp_path / "use.cpp"
+    src.write_text('#include "zoic_tile_buffer.hpp"\nint use(zoic_camera *c) { ZoicTileBuffer t(c, 64, 0); t.push(0, 0, 0.5f, 0.5f); return (int)t.size(); }\n')
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "arnold"), str(src)])
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "zoic_amd.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(zoic_[a-z0-9_]+)\s*\(", hdr))
+    code = re.sub(r"//.*", "", open(os.path.join(ROOT, "arnold", "zoic_tile_buffer.hpp")).read())
+    used = set(re.findall(r"\b(zoic_[a-z0-9_]+)\s*\(", code))
+    assert used and used <= declared, used - declared
