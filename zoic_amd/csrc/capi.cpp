@@ -151,7 +151,7 @@ struct CallContext {
     }
 };
 
-// The mailbox of the resident kernel (mailbox.hip): header + 64 request lines + 64 reply lines + 64 tile-done lines in ONE mapped,
+// The mailbox of the resident kernel (mailbox.hip): header + 64 request lines + 64 reply lines + the tiles' per-batch completion flags in ONE mapped,
 // page-locked allocation; the launch's device-side state (what each slot has answered, the control block, the tile jobs: they
 // survive its retirements); a private stream.
 struct Mailbox {
@@ -162,13 +162,22 @@ struct Mailbox {
     std::mutex slotM[kMailSlots];              // one call per slot at a time (tids 64 apart share a slot)
     uint32_t seq[kMailSlots] = {};
     uint32_t tileSeq[kMailSlots] = {};         // the tile in flight on the slot (0: none); under slotM
+    uint32_t tileBatches[kMailSlots] = {}, tileSeen[kMailSlots] = {};   // ... its 64-sample batches, and how many of their flags have been seen
     std::atomic<uint32_t> slotsInUse{0};       // slots the resident launch watches; written under launchM (0: not initialised)
     std::atomic<uint32_t> workerGroups{0};     // tile worker workgroups of the resident launch (0 until the camera sees its first tile)
     zoic_tile *ownTile[kMailSlots][2] = {};    // zoic_camera_create_rays_tile's staging for callers' pageable arrays (under slotM)
     volatile MailHeader *header() const { return static_cast<volatile MailHeader *>(mem.host); }
     volatile MailRequest *request(unsigned slot) const { return reinterpret_cast<volatile MailRequest *>(static_cast<char *>(mem.host) + kMailRequestsOffset) + slot; }
     volatile MailReply *reply(unsigned slot) const { return reinterpret_cast<volatile MailReply *>(static_cast<char *>(mem.host) + kMailRepliesOffset) + slot; }
-    volatile MailTileDone *tile_done(unsigned slot) const { return reinterpret_cast<volatile MailTileDone *>(static_cast<char *>(mem.host) + kMailTileDoneOffset) + slot; }
+    volatile uint32_t *tile_flags(unsigned slot) const { return reinterpret_cast<volatile uint32_t *>(static_cast<char *>(mem.host) + kMailTileFlagsOffset) + static_cast<size_t>(slot) * kTileMaxBatches; }
+    // every batch of the slot's tile has reported (non-blocking; remembers how far it got)
+    bool tile_complete(unsigned slot)
+    {
+        volatile uint32_t *f = tile_flags(slot);
+        uint32_t &seen = tileSeen[slot];
+        while (seen < tileBatches[slot] && f[seen] == tileSeq[slot]) ++seen;
+        return seen == tileBatches[slot];
+    }
     hipError_t init()
     {
         if (mem.host && dState && stream) return hipSuccess;
@@ -1240,8 +1249,7 @@ static zoic_status tile_settle_locked(zoic_camera *cam, unsigned slot)
     Mailbox &M = cam->mail;
     const uint32_t seq = M.tileSeq[slot];
     if (seq == 0u) return ZOIC_OK;
-    volatile MailTileDone *dn = M.tile_done(slot);
-    if (zoic_status s = mailbox_await(cam, slot, true, [&] { return dn->seq == seq; })) return s;
+    if (zoic_status s = mailbox_await(cam, slot, true, [&] { return M.tile_complete(slot); })) return s;
     std::atomic_thread_fence(std::memory_order_acquire);
     M.tileSeq[slot] = 0u;
     return ZOIC_OK;
@@ -1322,7 +1330,7 @@ static zoic_status tile_post_locked(zoic_camera *cam, unsigned slot, uint32_t n,
     q->inLo = static_cast<uint32_t>(dIn); q->inHi = static_cast<uint32_t>(dIn >> 32); q->n = n;
     std::atomic_thread_fence(std::memory_order_release);   // the caller's input rows and the words above, then the numbers
     q->seq2 = seq; q->seq1 = seq; q->seq0 = seq;
-    M.tileSeq[slot] = seq;
+    M.tileSeq[slot] = seq; M.tileBatches[slot] = (n + 63u) >> 6; M.tileSeen[slot] = 0u;
     *seqOut = seq;
     return ZOIC_OK;
 }
@@ -1397,7 +1405,7 @@ int zoic_tile_done(zoic_tile *tile)
     zoic_camera *cam = tile->cam;
     std::lock_guard<std::mutex> slotLock(cam->mail.slotM[tile->slot]);
     if (cam->mail.tileSeq[tile->slot] != tile->seq) return 1;
-    return cam->mail.tile_done(tile->slot)->seq == tile->seq ? 1 : 0;
+    return cam->mail.tile_complete(tile->slot) ? 1 : 0;
 }
 
 zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,

@@ -139,16 +139,11 @@ __device__ __forceinline__ V3 retry_direction(const KolbTable &T, V2 lens, float
 // third of the lanes.  A draw of exactly (0.5, 0.5) makes the concentric-disk sample NaN (zoic.cpp:697-699), and a NaN ray
 // PASSES every comparison of the reference's trace: such a ray (probability 2e-15 per draw) is a success with NaN origin /
 // direction at that try -- reproduced here; returns true in that case (the caller counts it as a success).
+// (the arithmetic, apart from the sample fetch and the record store: shared with the resident tile workers, mailbox.hip)
+struct DeadRayEnd { V3 o, d; float w; uint32_t tries; bool nanDraw; };
 template <bool STRICT>
-__device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
-                                                const float4 *__restrict__ samples, const uint4 *__restrict__ states, uint64_t rayBase,
-                                                RayRecord *__restrict__ out, uint32_t idx)
+__device__ __forceinline__ DeadRayEnd dead_ray_end(const KolbTable &T, const BokehTables &B, const float *bokehLds, const RaySetup &rs, Rng rng)
 {
-    const float4 s = samples[idx];
-    const RaySetup rs = setup_ray<STRICT>(T, lutLds, s.x, s.y);
-    Rng rng;
-    if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
-    else rng = rng_for_ray(T.seed, rayBase + idx);
     // retries 1 ... 26 (zoic.cpp:1927-1947), branch-free and unrolled: one dependent chain of 52 xorshift steps that the
     // scheduler interleaves with the (independent) set-up arithmetic above; the first draw at the disk's centre, if any, is
     // remembered instead of leaving the loop (finish kernel 126 -> 113 us on C2; two rays per lane, to run two chains side
@@ -161,17 +156,33 @@ __device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehT
         const bool centre = ((a - 0x7fffffc0u) <= 0xc0u) & ((b - 0x7fffffc0u) <= 0xc0u);
         hitTry = (centre && hitTry == 0u) ? k : hitTry;
     }
-    const bool nanDraw = !T.useImage && hitTry != 0u;
-    if (nanDraw) tries = hitTry;
+    DeadRayEnd e;
+    e.nanDraw = !T.useImage && hitTry != 0u;
+    if (e.nanDraw) tries = hitTry;
     const float qnan = __builtin_bit_cast(float, 0x7fc00000u);
-    float w = nanDraw ? 1.0f : 0.0f;
-    if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
-    V3 o{rs.o0x, rs.o0y, T.originShift}, d{qnan, qnan, qnan};
-    if (nanDraw) o = V3{qnan, qnan, qnan};
-    else d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, rng_unit(a), rng_unit(b)), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-    store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
-                     1u | (tries << 1) | ((rs.flags & 1u) << 6));
-    return nanDraw;
+    e.w = e.nanDraw ? 1.0f : 0.0f;
+    if (T.exposureOn) e.w *= T.exposureMul;                                            // zoic.cpp:1981-1987
+    e.o = V3{rs.o0x, rs.o0y, T.originShift}; e.d = V3{qnan, qnan, qnan};
+    if (e.nanDraw) e.o = V3{qnan, qnan, qnan};
+    else e.d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, rng_unit(a), rng_unit(b)), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+    e.tries = tries;
+    return e;
+}
+
+template <bool STRICT>
+__device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
+                                                const float4 *__restrict__ samples, const uint4 *__restrict__ states, uint64_t rayBase,
+                                                RayRecord *__restrict__ out, uint32_t idx)
+{
+    const float4 s = samples[idx];
+    const RaySetup rs = setup_ray<STRICT>(T, lutLds, s.x, s.y);
+    Rng rng;
+    if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
+    else rng = rng_for_ray(T.seed, rayBase + idx);
+    const DeadRayEnd e = dead_ray_end<STRICT>(T, B, bokehLds, rs, rng);
+    store_ray_record(out, idx, e.o.x * -1.0f, e.o.y * -1.0f, e.o.z * -1.0f, e.d.x * -1.0f, e.d.y * -1.0f, e.d.z * -1.0f, e.w,   // zoic.cpp:1960-1961
+                     1u | (e.tries << 1) | ((rs.flags & 1u) << 6));
+    return e.nanDraw;
 }
 
 

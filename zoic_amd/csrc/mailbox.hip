@@ -67,43 +67,120 @@ __device__ __forceinline__ void store_uncached(uint4 *p, uint4 q)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
-struct OneRay { V3 o, d; float w; uint32_t tries, lutMiss, tir; bool unsure; };
+struct LaneRay { V3 o, d; float w; uint32_t tries, lutMiss, tir; bool vignetted; };
 
-// camera_create_ray's RAYTRACED branch for ONE sample (zoic.cpp:1850-1964), the reference's loop as it stands: trace, and
-// while the trace fails and tries <= 25 draw the next lens sample.  GUARD: `unsure` is set when a decision lay inside its
-// guard band (fast_optics.hpp) -- the caller then evaluates the ray again in STRICT.
+// camera_create_ray's RAYTRACED branch (zoic.cpp:1850-1964) for the (up to) 64 samples a wave holds, one ray per lane, in the batch
+// kernels' ORDER OF WORK (kolb_pool_body.hpp) without their pool -- a tile's batch stays in its lanes until its last ray is done:
+//   * set-up once at full width; then rounds of { candidate search: a lane draws lens samples until one clears interface 0 (a tenth of
+//     a try: most rejected tries die there) or it runs out of tries; ONE trace for the lanes that hold a candidate }.  The wave's time is
+//     the number of ROUNDS -- the deepest chain of tries that got past the rear element -- not the largest try count of its 64 rays
+//     (the reference's loop as it stands, one ray per lane, measured 46 us per batch: every ray waits for the unluckiest one's 26
+//     whole traces);
+//   * dead pixels (outside the image circle all 27 tries are one) and retry-dead rays (dead_ray_end: no retry can reach the rear
+//     element) end at their first failure as they do in the batch kernels;
+//   * GUARD (decision-safe FAST): a ray with a decision inside a guard band stops where it stands and is evaluated by the listed
+//     kernel's rule (listed_one_ray), on the spot.
+// Every try is evaluated by the same device functions as everywhere else in the library: same bits as the batch kernels and as the
+// reference's loop order (tests/test_tile_gpu.py, tests/test_boundary_gpu.py).  rng: the ray's retry stream at its first draw.
 template <bool STRICT>
-__device__ __forceinline__ OneRay kolb_one_ray(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
-                                               float4 s, Rng rng, bool guard)
+__device__ __forceinline__ LaneRay kolb_wave_rays(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds, float4 s,
+                                                  Rng rng, bool active, bool guard)
 {
-    OneRay r;
+    constexpr uint32_t kOut = static_cast<uint32_t>(kMaxTries) + 1u;   // tries of a ray that ran out (zoic.cpp:1927: tries <= 25)
+    LaneRay r;
+    const Rng rng0 = rng;
     const RaySetup rs = setup_ray<STRICT>(T, lutLds, s.x, s.y);
-    r.lutMiss = rs.flags & 1u; r.tir = 0; r.tries = 0;
-    r.unsure = guard && T.useLUT && rs.lutEdge;
+    r.lutMiss = rs.flags & 1u; r.tir = 0; r.tries = 0; r.vignetted = false;
+    bool unsure = guard && T.useLUT && rs.lutEdge;
     const V3 o0{rs.o0x, rs.o0y, T.originShift};
     V2 lens = lens_sample<STRICT>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
+    bool finiteSample = true;
+    if (rs.dead) {   // whatever finite point the sampler returns, the direction is (0 - o.x, 0 - o.y, dirZ) (kolb_pool_body.hpp)
+        const bool plainSample = (s.z >= 0.0f) & (s.z < 1.0f) & (s.w >= 0.0f) & (s.w < 1.0f) & !((s.z == 0.5f) & (s.w == 0.5f));
+        if (plainSample) lens = V2{0.0f, 0.0f};
+        finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
+    }
+    V3 d;
     if (!T.useLUT) {                                           // zoic.cpp:1873-1877
-        r.d = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};
+        d = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};
     } else {                                                   // zoic.cpp:1913-1924: x-only translation on the first sample
         lens.x *= rs.maxScale; lens.y *= rs.maxScale;
         lens.x += rs.translation;
         const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
-        r.d = V3{rx - o0.x, ry - o0.y, T.dirZ};
+        d = V3{rx - o0.x, ry - o0.y, T.dirZ};
     }
-    r.o = o0;
-    for (;;) {
-        bool ok, near = false;
-        if constexpr (STRICT) ok = trace_lens_strict(T, r.o, r.d, r.tir);
-        else ok = trace_lens_fast_rolled(T, r.o, r.d, r.tir, guard ? &near : nullptr);
-        r.unsure |= near;
-        if (ok || r.tries > static_cast<uint32_t>(kMaxTries)) break;   // zoic.cpp:1879 / 1927
-        r.o = o0;
-        const float u = rng_unit(xor128(rng));                  // zoic.cpp:1930
+    V3 o = o0;
+    const bool deadPixel = rs.dead && finiteSample, retryDead = (rs.flags & kRetryDeadBit) != 0u;
+    bool live = active && !unsure, endDead = false;
+    const auto clears_rear = [&](const V3 &dd, bool &near0) {
+        if constexpr (STRICT) {
+            near0 = false;
+            bool inRange;
+            bool p = interface0_clear_strict_lean(T, o0, dd, inRange);
+            if (__builtin_expect(!inRange, 0)) p = interface0_clear_strict(T, o0, dd);   // never seen: guarded roots
+            return p;
+        } else {
+            bool p;
+            if (guard) p = interface0_clear_fast<true>(T.fsurf[0], o0, dd, near0);
+            else p = interface0_clear_fast<false>(T.fsurf[0], o0, dd, near0);
+            return p;
+        }
+    };
+    const auto draw = [&]() {                                   // zoic.cpp:1930-1943
+        const float u = rng_unit(xor128(rng));
         const float v = rng_unit(xor128(rng));
-        r.d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
         ++r.tries;
+        d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+    };
+    // what a FAILED try does next: the shortcuts of a ray's first failure, out of tries, or the next draw.  Returns false when the ray ends.
+    const auto after_failure = [&](uint32_t tirTry) {
+        if (r.tries == 0u && deadPixel) { r.tir += kOut * tirTry; r.tries = kOut; return false; }   // 26 more identical failures
+        if (r.tries == 0u && retryDead) { endDead = true; return false; }
+        if (r.tries > static_cast<uint32_t>(kMaxTries)) return false;
+        draw();
+        return true;
+    };
+    while (__ballot(live) != 0ull) {
+        bool cand = false, searching = live;
+        while (__ballot(searching) != 0ull) {
+            if (searching) {
+                bool near0 = false;
+                const bool pass0 = clears_rear(d, near0);
+                if (near0) { unsure = true; live = false; searching = false; }
+                else if (pass0) { cand = true; searching = false; }
+                else if (!after_failure(0u)) { o = o0; live = false; searching = false; }   // a clip at interface 0 leaves (o, d) untouched
+            }
+        }
+        if (cand) {
+            V3 ot = o0, dt = d;
+            uint32_t tirTry = 0;
+            bool ok, near = false;
+            if constexpr (STRICT) ok = trace_lens_strict(T, ot, dt, tirTry);
+            else ok = trace_lens_fast_rolled(T, ot, dt, tirTry, guard ? &near : nullptr);
+            if (near) { unsure = true; live = false; }
+            else {
+                r.tir += tirTry;
+                if (ok) { o = ot; d = dt; live = false; }
+                else {
+                    if (!after_failure(tirTry)) { if (!endDead) { o = ot; d = dt; } live = false; }   // the reference's partial state (zoic.cpp:1951-1961)
+                }
+            }
+        }
     }
-    r.w = (r.tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;   // zoic.cpp:1951-1957
+    if (endDead) {   // a retry-dead ray whose first try failed: tries 1 ... 26 die at interface 0; the state of the last draw
+        const DeadRayEnd e = dead_ray_end<STRICT>(T, B, bokehLds, rs, rng0);
+        r.o = e.o; r.d = e.d; r.w = e.w; r.tries = e.tries; r.vignetted = !e.nanDraw;
+        return r;
+    }
+    if (unsure) {    // a decision too close to call: the ray is evaluated as the batch path's listed kernel does it (same rule, same bits)
+        const ListedRay q = listed_one_ray(T, B, lutLds, bokehLds, s, rng0);
+        r.o = q.o; r.d = q.d; r.w = q.w; r.tries = q.tries; r.lutMiss = q.lutMiss; r.tir = q.tir;
+        r.vignetted = r.tries > static_cast<uint32_t>(kMaxTries);
+        return r;
+    }
+    r.o = o; r.d = d;
+    r.vignetted = r.tries > static_cast<uint32_t>(kMaxTries);
+    r.w = r.vignetted ? 0.0f : 1.0f;                                    // zoic.cpp:1951-1957
     if (T.exposureOn) r.w *= T.exposureMul;                             // zoic.cpp:1981-1987
     return r;
 }
@@ -115,6 +192,19 @@ __device__ __forceinline__ uint32_t load_sys(const uint32_t *p) { return __hip_a
 __device__ __forceinline__ void store_sys(uint32_t *p, uint32_t v) { __hip_atomic_store((GlobalWord *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 template <class V> __device__ __forceinline__ V load_dev(const V *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class V> __device__ __forceinline__ void store_dev(V *p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes of the job table in one instruction, past the non-coherent caches (sc1: device scope)
+__device__ __forceinline__ void load_dev4x3(const uint4 *p, uint4 &a, uint4 &b, uint4 &c)   // p[0], p[1], p[2]: ONE wait for the three
+{
+    u32x4 x, y, z;
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\tglobal_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+                 "s_waitcnt vmcnt(0)" : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(p) : "memory");
+    a = make_uint4(x.x, x.y, x.z, x.w); b = make_uint4(y.x, y.y, y.z, y.w); c = make_uint4(z.x, z.y, z.z, z.w);
+}
+__device__ __forceinline__ void store_dev4(uint4 *p, uint4 q)
+{
+    const u32x4 v = {q.x, q.y, q.z, q.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ uint32_t first_lane(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 __device__ __forceinline__ unsigned long long first_lane64(unsigned long long v)
 {
@@ -157,7 +247,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
     MailHeader *header = reinterpret_cast<MailHeader *>(mapped);
     const MailRequest *requests = reinterpret_cast<const MailRequest *>(mapped + kMailRequestsOffset);
     MailReply *replies = reinterpret_cast<MailReply *>(mapped + kMailRepliesOffset);
-    MailTileDone *tileDone = reinterpret_cast<MailTileDone *>(mapped + kMailTileDoneOffset);
+    uint32_t *tileFlags = reinterpret_cast<uint32_t *>(mapped + kMailTileFlagsOffset);   // [slot][batch]: the tile's sequence number when the batch's rows are complete
     uint32_t *control = st->control;
     unsigned long long *workMask = reinterpret_cast<unsigned long long *>(control + 4);
     volatile unsigned long long *lastCall = reinterpret_cast<volatile unsigned long long *>(control + 2);
@@ -182,7 +272,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         uint32_t work = 0;      // 1: one sample (slot role), 2: one 64-sample batch of a tile
         float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         Rng rng{1u, 2u, 3u, 4u};
-        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobBatches = 0, jobSeq = 0;
+        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobSeq = 0;
         unsigned long long jobIn = 0, jobOut = 0, jobBase = 0;
         if (slotRole && !ownJob) {
             u32x4 line, ctl;   // ctl: the launch's control block = {exit flag, waves out, time of the last call (lo, hi)}
@@ -204,31 +294,36 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 continue;
             }
             if (lane == 0) *lastCall = now;
+            mine = seq;
             if (lane_word(line.z, 2) == 0u) {   // ---- one sample
                 work = 1;
                 s = make_float4(__builtin_bit_cast(float, lane_word(line.x, 0)), __builtin_bit_cast(float, lane_word(line.y, 0)),
                                 __builtin_bit_cast(float, lane_word(line.z, 0)), __builtin_bit_cast(float, lane_word(line.x, 1)));
                 rng = Rng{lane_word(line.y, 1), lane_word(line.z, 1), lane_word(line.x, 2), lane_word(line.y, 2)};
             } else {                            // ---- a tile: {inLo, inHi, n, seq} {outLo, outHi, baseLo, seq} {baseHi, -, kind, seq}
-                const uint32_t n = lane_word(line.z, 0);
-                const uint32_t batches = (n + 63u) >> 6;
-                if (lane == 0) {
-                    TileJob *J = st->jobs + slot;
-                    store_dev(&J->in, (static_cast<unsigned long long>(lane_word(line.y, 0)) << 32) | lane_word(line.x, 0));
-                    store_dev(&J->out, (static_cast<unsigned long long>(lane_word(line.y, 1)) << 32) | lane_word(line.x, 1));
-                    store_dev(&J->base, (static_cast<unsigned long long>(lane_word(line.x, 2)) << 32) | lane_word(line.z, 1));
-                    store_dev(&J->n, n); store_dev(&J->batches, batches); store_dev(&J->seq, seq);
-                    store_dev(&st->tickets[slot].done, 0u);
-                    // descriptor before ticket: whoever draws a ticket of generation `seq` reads this descriptor.  The ticket
-                    // and the mask bit need no order between them (a worker that sees the bit first draws a stale ticket and comes back)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    store_dev(&st->tickets[slot].next, static_cast<unsigned long long>(seq) << 32);
-                    if (batches != 0u) (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else store_uncached(reinterpret_cast<uint4 *>(tileDone + slot), make_uint4(0u, 0u, 0u, seq));   // an empty tile is done
+                jobN = lane_word(line.z, 0);
+                jobIn = (static_cast<unsigned long long>(lane_word(line.y, 0)) << 32) | lane_word(line.x, 0);
+                jobOut = (static_cast<unsigned long long>(lane_word(line.y, 1)) << 32) | lane_word(line.x, 1);
+                jobBase = (static_cast<unsigned long long>(lane_word(line.x, 2)) << 32) | lane_word(line.z, 1);
+                jobSeq = seq; jobSlot = slot; batch = 0;
+                if (jobN == 0u) continue;       // (the host never posts an empty tile)
+                work = 2;                       // batch 0 is this wave's, straight from the request: a tile of up to 64 samples involves nobody else
+                if (jobN > 64u) {
+                    // the rest is POSTED for the workers: descriptor (three 16-byte chunks, each ending in the tile's number, like a
+                    // request line), then the ticket counter at batch 1, then the slot's bit.  Whoever draws a ticket of generation
+                    // `seq` finds this descriptor; the ticket and the bit need no order between them (a worker that sees the bit first
+                    // draws a stale ticket and comes back).
+                    if (lane == 0) {
+                        uint4 *J = reinterpret_cast<uint4 *>(st->jobs + slot);
+                        store_dev4(J, make_uint4(lane_word(line.x, 0), lane_word(line.y, 0), jobN, seq));
+                        store_dev4(J + 1, make_uint4(lane_word(line.x, 1), lane_word(line.y, 1), lane_word(line.z, 1), seq));
+                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), (jobN + 63u) >> 6, 0u, seq));
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        store_dev(&st->tickets[slot].next, (static_cast<unsigned long long>(seq) << 32) | 1ull);
+                        (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ownJob = true;
                 }
-                mine = seq;
-                ownJob = batches != 0u;
-                continue;
             }
         }
         if (work == 0u) {   // ---- draw a batch: a slot's wave from its own tile, a worker from any slot with its bit set
@@ -236,31 +331,41 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             else {
                 const unsigned long long mask = first_lane64(load_dev(workMask));
                 if (mask == 0ull) {
-                    if ((++idlePolls & 3u) == 0u && first_lane(load_dev(control)) != 0u) break;   // exit flag: only with nothing left to hand out
-                    if (idlePolls < 64u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);   // ~0.2 us while tiles keep coming, ~0.9 us when they do not
+                    if ((++idlePolls & 7u) == 0u && first_lane(load_dev(control)) != 0u) break;   // exit flag: only with nothing left to hand out
+                    __builtin_amdgcn_s_sleep(4);   // the launch only lives while calls keep coming (1 ms): no point in polling slowly
                     continue;
                 }
-                idlePolls = 0;
                 const uint32_t r = waveId & 63u;   // every worker starts its search at another slot
                 const unsigned long long rot = r ? ((mask >> r) | (mask << (64u - r))) : mask;
                 jobSlot = (static_cast<uint32_t>(__builtin_ctzll(rot)) + r) & 63u;
             }
+            // the ticket and -- speculatively, in the same round trip -- the descriptor
+            const uint4 *J = reinterpret_cast<const uint4 *>(st->jobs + jobSlot);
             unsigned long long t = 0;
             if (lane == 0) t = __hip_atomic_fetch_add(&st->tickets[jobSlot].next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint4 c0, c1, c2;
+            load_dev4x3(J, c0, c1, c2);
             t = first_lane64(t);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const TileJob *J = st->jobs + jobSlot;
-            jobSeq = first_lane(load_dev(&J->seq));
-            jobBatches = first_lane(load_dev(&J->batches));
+            const uint32_t gen = static_cast<uint32_t>(t >> 32);
+            if (first_lane(c0.w) != gen || first_lane(c1.w) != gen || first_lane(c2.w) != gen) {
+                // read before the poster's stores were visible -- or a ticket of a tile that is long done: once more, behind the ticket
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                load_dev4x3(J, c0, c1, c2);
+            }
             batch = static_cast<uint32_t>(t);
-            if (jobSeq != static_cast<uint32_t>(t >> 32) || batch >= jobBatches) {   // a ticket of a tile that has been handed out already
-                if (slotRole) ownJob = false; else __builtin_amdgcn_s_sleep(2);
+            const uint32_t batches = first_lane(c2.y);
+            if (first_lane(c0.w) != gen || first_lane(c1.w) != gen || first_lane(c2.w) != gen || batch >= batches) {   // nothing left of that tile
+                if (slotRole) ownJob = false; else __builtin_amdgcn_s_sleep(1);
                 continue;
             }
             // the LAST valid ticket clears the slot's bit: the tile cannot complete (and the slot post another) before this wave is done
-            if (batch + 1u == jobBatches && lane == 0) (void)__hip_atomic_fetch_and(workMask, ~(1ull << jobSlot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            jobN = first_lane(load_dev(&J->n));
-            jobIn = first_lane64(load_dev(&J->in)); jobOut = first_lane64(load_dev(&J->out)); jobBase = first_lane64(load_dev(&J->base));
+            if (batch + 1u == batches && lane == 0) (void)__hip_atomic_fetch_and(workMask, ~(1ull << jobSlot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            jobSeq = gen;
+            jobN = first_lane(c0.z);
+            jobIn = (static_cast<unsigned long long>(first_lane(c0.y)) << 32) | first_lane(c0.x);
+            jobOut = (static_cast<unsigned long long>(first_lane(c1.y)) << 32) | first_lane(c1.x);
+            jobBase = (static_cast<unsigned long long>(first_lane(c2.x)) << 32) | first_lane(c1.z);
+            idlePolls = 0;
             work = 2;
         }
 
@@ -288,12 +393,12 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             rayIndex = jobBase + first + lane;
         }
 
-        // ---- the rays (ONE site for both kinds of work: the reference's loop, one ray per lane) ---------------------------------
+        // ---- the rays (ONE site for both kinds of work) -------------------------------------------------------------------------
         V3 o{0.0f, 0.0f, 0.0f}, d{0.0f, 0.0f, 0.0f};
         float w = 0.0f;
         uint32_t tries = 0, lutMiss = 0;
-        if (active) {
-            if (model == 0) {   // THINLENS, zoic.cpp:1771-1846
+        if (model == 0) {   // THINLENS, zoic.cpp:1771-1846
+            if (active) {
                 ThinRay r;
                 if (work == 2u) {   // a tile's ray = the batch kernels' ray: its own stream, seeded at its first redraw; FAST where they run FAST
                     Rng q{1u, 2u, 3u, 4u};
@@ -305,21 +410,15 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 }
                 o = r.origin; d = r.dir; w = r.w; tries = r.tries;
                 if (Th.useDof) { if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ; }
-            } else {
-                if (work == 2u) rng = rng_for_ray(T.seed, rayIndex);
-                OneRay r;
-                if (mode == 0) r = kolb_one_ray<true>(T, B, lutLds, bokehLds, s, rng, false);
-                else {
-                    r = kolb_one_ray<false>(T, B, lutLds, bokehLds, s, rng, mode == 1);
-                    if (r.unsure) {   // a decision too close to call: the ray is evaluated as the batch path's listed kernel does it
-                        const ListedRay q = listed_one_ray(T, B, lutLds, bokehLds, s, rng);   // (kolb_listed_body.hpp: same rule, same bits)
-                        r.o = q.o; r.d = q.d; r.w = q.w; r.tries = q.tries; r.lutMiss = q.lutMiss; r.tir = q.tir;
-                    }
-                }
-                o = V3{r.o.x * -1.0f, r.o.y * -1.0f, r.o.z * -1.0f}; d = V3{r.d.x * -1.0f, r.d.y * -1.0f, r.d.z * -1.0f};   // zoic.cpp:1960-1961
-                w = r.w; tries = r.tries; lutMiss = r.lutMiss; tir += r.tir;
-                if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ;
             }
+        } else {            // RAYTRACED: every lane takes part in the wave's rounds (kolb_wave_rays); idle lanes ride along
+            if (work == 2u) rng = rng_for_ray(T.seed, rayIndex);
+            LaneRay r;
+            if (mode == 0) r = kolb_wave_rays<true>(T, B, lutLds, bokehLds, s, rng, active, false);
+            else r = kolb_wave_rays<false>(T, B, lutLds, bokehLds, s, rng, active, mode == 1);
+            o = V3{r.o.x * -1.0f, r.o.y * -1.0f, r.o.z * -1.0f}; d = V3{r.d.x * -1.0f, r.d.y * -1.0f, r.d.z * -1.0f};   // zoic.cpp:1960-1961
+            w = r.w; tries = r.tries; lutMiss = r.lutMiss;
+            if (active) { tir += r.tir; if (r.vignetted) ++vign; else ++succ; }
         }
         const uint32_t flags = (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6);
 
@@ -331,7 +430,6 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 store_uncached(a + 1, make_uint4(__builtin_bit_cast(uint32_t, d.x), __builtin_bit_cast(uint32_t, d.y), __builtin_bit_cast(uint32_t, d.z), seq));
                 store_uncached(a + 2, make_uint4(__builtin_bit_cast(uint32_t, w), flags, 0u, seq));
             }
-            mine = seq;
             continue;
         }
         // AtCameraOutput rows (84 bytes = 21 floats: origin, dir, dOdx, dOdy, dDdx, dDdy, weight[3]) as zoic_create_rays_arnold
@@ -361,16 +459,10 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             }
             wave_lds_fence();
         }
-        // this wave's rows are visible to the host before its batch counts as done; the wave that counts the tile's last batch has
-        // seen every other wave's count (and, through it, their releases) and reports the tile
+        // the batch's rows are released at system scope; then its flag says so to the render thread (which waits for every flag of
+        // its tile: no counter, no last wave, nobody waits for anybody on the device)
         __threadfence_system();
-        uint32_t before = 0;
-        if (lane == 0) before = __hip_atomic_fetch_add(&st->tickets[jobSlot].done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        before = first_lane(before);
-        if (before + 1u == jobBatches) {
-            __threadfence_system();
-            if (lane == 0) store_uncached(reinterpret_cast<uint4 *>(tileDone + jobSlot), make_uint4(jobN, jobBatches, 0u, jobSeq));
-        }
+        if (lane == 0) store_sys(tileFlags + jobSlot * kTileMaxBatches + batch, jobSeq);
     }
     for (int off = 32; off > 0; off >>= 1) { succ += __shfl_xor(succ, off, 64); vign += __shfl_xor(vign, off, 64); tir += __shfl_xor(tir, off, 64); }
     if (lane == 0) {

@@ -39,32 +39,30 @@ struct alignas(64) MailReply {                // the number is the LAST word of 
     float weight; uint32_t flags, pad2, seq2; // zoic_ray::weight / flags
     uint32_t fill[4];
 };
-// a tile's completion: ONE 16-byte chunk written by the wave that finished the tile's last batch, behind a system-scope release
-// of every wave's output rows
-struct alignas(64) MailTileDone {
-    uint32_t n, batches, pad, seq;
-    uint32_t fill[12];
-};
 struct alignas(64) MailHeader {
     uint32_t pad0[2], slotsInUse, workerGroups;   // chunk 0: written by the host only, read once by every wave of a launch
     uint32_t alive, pad2[3];                      // chunk 1: set by the host before a launch, cleared by the kernel as its last act
     uint32_t fill[8];
 };
-static_assert(sizeof(MailRequest) == 64 && sizeof(MailTileRequest) == 64 && sizeof(MailReply) == 64 && sizeof(MailHeader) == 64 &&
-              sizeof(MailTileDone) == 64, "mailbox layout");
+static_assert(sizeof(MailRequest) == 64 && sizeof(MailTileRequest) == 64 && sizeof(MailReply) == 64 && sizeof(MailHeader) == 64, "mailbox layout");
 // byte offsets into the mapped allocation
+// (tile flags: one word per 64-sample batch of a slot's tile -- the tile's sequence number once the batch's rows are complete, written
+// by the wave that made them behind a system-scope release; the render thread waits for all of its tile's)
+constexpr uint32_t kTileMaxBatches = kTileMaxSamples / 64u;
 constexpr size_t kMailRequestsOffset = 64, kMailRepliesOffset = kMailRequestsOffset + 64 * kMailSlots,
-                 kMailTileDoneOffset = kMailRepliesOffset + 64 * kMailSlots, kMailBytes = kMailTileDoneOffset + 64 * kMailSlots;
+                 kMailTileFlagsOffset = kMailRepliesOffset + 64 * kMailSlots, kMailBytes = kMailTileFlagsOffset + 4u * kTileMaxBatches * kMailSlots;
 
 // Device-memory state of the resident launch (survives its retirements): what a slot has answered, the launch's control block,
 // and the tile jobs the slot waves post for the workers.
-struct alignas(64) TileJob {                  // written by the slot's wave, read by whoever holds a ticket of generation `seq`
-    unsigned long long in, out, base;
-    uint32_t n, batches, seq, pad[7];
+struct alignas(64) TileJob {                  // three 16-byte chunks, each ending in the tile's sequence number (like a request line):
+    uint32_t inLo, inHi, n, seq0;             // written by the slot's wave, read -- in the same round trip as the ticket -- by whoever
+    uint32_t outLo, outHi, baseLo, seq1;      // draws one; a descriptor whose three numbers equal the ticket's generation is that tile's
+    uint32_t baseHi, batches, pad, seq2;
+    uint32_t fill[4];
 };
 struct alignas(64) TileTicket {               // (generation << 32) | next batch: one atomicAdd hands a batch out
     unsigned long long next;
-    uint32_t done, pad[13];                   // batches finished (the wave that makes it `batches` reports the tile)
+    uint32_t pad[14];
 };
 struct MailDeviceState {
     uint32_t served[kMailSlots];              // sequence number of the last call each slot answered
