@@ -333,6 +333,20 @@ struct zoic_tile {
 void Mailbox::release()
 {
     (void)stop();
+#ifdef ZOIC_TILE_TIMING   // (tools/: -DZOIC_TILE_TIMING builds print where a tile batch's time went when the camera is destroyed)
+    if (dState) {
+        unsigned long long t[16];
+        if (hipMemcpy(t, dState->timing, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (t[4])
+                std::fprintf(stderr, "worker batches since the slot wave saw the request: start avg %.2f us (max %.2f), flag written avg %.2f us (max %.2f)\n",
+                             t[8] * 0.01 / t[4], t[9] * 0.01, t[10] * 0.01 / t[4], t[11] * 0.01);
+            for (int o = 0; o < 8; o += 4)
+                if (t[o])
+                    std::fprintf(stderr, "tile timing (%s waves): %llu batches, input %.2f us, rays %.2f us, output %.2f us per batch\n", o ? "worker" : "slot", t[o],
+                                 t[o + 1] * 0.01 / t[o], t[o + 2] * 0.01 / t[o], t[o + 3] * 0.01 / t[o]);
+        }
+    }
+#endif
     for (auto &pair : ownTile) for (zoic_tile *&t : pair) if (t) { t->mem.release(); delete t; t = nullptr; }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
     if (dState) { (void)hipFree(dState); dState = nullptr; }
@@ -1198,7 +1212,7 @@ static zoic_status mailbox_ensure_running(zoic_camera *cam, unsigned slot, bool 
         if (moreSlots) { h->slotsInUse = slot + 1; M.slotsInUse.store(slot + 1, std::memory_order_release); }
         if (moreWorkers) {
             uint32_t groups = kTileWorkerGroups;
-            if (const char *env = std::getenv("ZOIC_TILE_WORKER_GROUPS")) { const long v = std::atol(env); if (v >= 1 && v <= 1024) groups = static_cast<uint32_t>(v); }
+            if (const char *env = std::getenv("ZOIC_TILE_WORKER_GROUPS")) { const long v = std::atol(env); if (v >= 1 && v <= static_cast<long>(kTileMaxWorkerWaves / 4u)) groups = static_cast<uint32_t>(v); }
             h->workerGroups = groups;
             M.workerGroups.store(groups, std::memory_order_release);
         }
@@ -1330,7 +1344,8 @@ static zoic_status tile_post_locked(zoic_camera *cam, unsigned slot, uint32_t n,
     q->inLo = static_cast<uint32_t>(dIn); q->inHi = static_cast<uint32_t>(dIn >> 32); q->n = n;
     std::atomic_thread_fence(std::memory_order_release);   // the caller's input rows and the words above, then the numbers
     q->seq2 = seq; q->seq1 = seq; q->seq0 = seq;
-    M.tileSeq[slot] = seq; M.tileBatches[slot] = (n + 63u) >> 6; M.tileSeen[slot] = 0u;
+    const uint32_t perBatch = cam->params.p.lensModel == ZOIC_THINLENS ? kTileRaysThin : kTileRaysRaytraced;   // (mailbox.hip)
+    M.tileSeq[slot] = seq; M.tileBatches[slot] = (n + perBatch - 1u) / perBatch; M.tileSeen[slot] = 0u;
     *seqOut = seq;
     return ZOIC_OK;
 }

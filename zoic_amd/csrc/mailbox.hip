@@ -14,16 +14,24 @@
 //   * ONE SAMPLE (kind 0): the slot's wave evaluates the ray with one lane -- the reference's own loop, STRICT or FAST arithmetic
 //     (optics.hpp / fast_optics.hpp; a FAST ray with a decision inside a guard band is re-evaluated on the spot by the listed
 //     kernel's rule, kolb_listed_body.hpp) -- and writes the REPLY line: three 16-byte chunks, sequence number last;
-//   * A TILE (kind 1: n <= 65536 AtCameraInput rows in mapped host memory -> n AtCameraOutput rows in mapped host memory): the
-//     slot's wave POSTS the tile as a job in device memory -- descriptor, a ticket counter (generation << 32 | next batch), a bit
-//     in the launch's 64-bit work mask -- and the WORKER waves of the launch (kTileWorkerGroups x 4, started with the first tile a
-//     camera sees) take 64-sample batches off it with one atomicAdd each, the slot's wave among them.  A batch is evaluated at
-//     FULL LANE WIDTH by the same device functions as a single sample (one ray per lane; ray i draws its retries from the stream
-//     keyed by base + i exactly as the batch kernels do, so a tile equals zoic_create_rays_arnold bit for bit): the 28-byte input
-//     rows arrive as 7 coalesced dword loads per lane across PCIe and are transposed through LDS, the 84-byte output rows leave
-//     as 21 coalesced dword stores per lane.  Every wave releases its rows at system scope before it counts its batch done; the
-//     wave that counts the last one writes the slot's TILE-DONE line.  No launch, no stream, no synchronise: a 4096-sample tile
-//     is answered in ~15 us where a launch-based call took 76;
+//   * A TILE (kind 1: n <= 65536 AtCameraInput rows in mapped host memory -> n AtCameraOutput rows in mapped host memory) is cut
+//     into BATCHES (RAYTRACED 16 samples, THINLENS 64).  The slot's wave takes batch 0 itself, straight from the request -- a tile of
+//     one batch involves nobody else -- and POSTS the rest as a job in device memory: a descriptor (three 16-byte chunks, each ending
+//     in the tile's number, like a request line), ticket counters (generation << 32 | next batch; up to 32 partitions of about eight
+//     batches: same-address atomics across the XCDs queue up at ~0.1 us each), a bit in the launch's 64-bit work mask; then it WAKES
+//     as many WORKER waves of the launch (kTileWorkerGroups x 4, started with the first tile a camera sees) as there are batches
+//     left, each through its own line in device memory with the partition it should start on (a thousand waves polling one word
+//     slowed every poll down).  A woken worker draws a ticket and -- in the same round trip -- reads the descriptor; a descriptor
+//     whose three numbers equal the ticket's generation is that tile's.  Lost wake-ups only cost time: the slot's wave keeps drawing
+//     tickets of its own tile until every batch is handed out, and a worker that runs out of batches looks at the work mask for
+//     other tiles.  A batch's 28-byte input rows arrive as coalesced dword loads across PCIe and are transposed through LDS, its
+//     84-byte output rows leave as coalesced dword stores (whole rows, as zoic_create_rays_arnold writes them); the wave releases
+//     them at system scope and then writes the batch's FLAG -- the tile's number -- in mapped host memory.  The render thread waits
+//     for all flags of its tile: no counter, no last wave, nobody waits for anybody on the device.  No launch, no stream, no
+//     synchronise: a 4096-sample tile is answered in 25-40 us (thin lens: 19 us) where a launch-based call took 76-122, and 16
+//     render threads with 65536-sample tiles run at the PCIe rate of the rows (bench.py host_path.tile);
+//   * the rays of a batch: kolb_wave_rays below (the tries of a ray side by side: a resident wave is alone on its SIMD and waits
+//     for its longest dependent chain, not for its instruction count);
 //   * the kernel retires by itself after 1 ms without a call and after 50 ms in any case (a resident kernel would stall the
 //     application's hipDeviceSynchronize / hipFree for ever); the next call finds `alive == 0` and launches it again
 //     (~20 us, once).  node_update / node_finish / the counter getters stop it first.  A wave never leaves with a batch in hand,
@@ -67,122 +75,208 @@ __device__ __forceinline__ void store_uncached(uint4 *p, uint4 q)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
-struct LaneRay { V3 o, d; float w; uint32_t tries, lutMiss, tir; bool vignetted; };
-
-// camera_create_ray's RAYTRACED branch (zoic.cpp:1850-1964) for the (up to) 64 samples a wave holds, one ray per lane, in the batch
-// kernels' ORDER OF WORK (kolb_pool_body.hpp) without their pool -- a tile's batch stays in its lanes until its last ray is done:
-//   * set-up once at full width; then rounds of { candidate search: a lane draws lens samples until one clears interface 0 (a tenth of
-//     a try: most rejected tries die there) or it runs out of tries; ONE trace for the lanes that hold a candidate }.  The wave's time is
-//     the number of ROUNDS -- the deepest chain of tries that got past the rear element -- not the largest try count of its 64 rays
-//     (the reference's loop as it stands, one ray per lane, measured 46 us per batch: every ray waits for the unluckiest one's 26
-//     whole traces);
-//   * dead pixels (outside the image circle all 27 tries are one) and retry-dead rays (dead_ray_end: no retry can reach the rear
-//     element) end at their first failure as they do in the batch kernels;
-//   * GUARD (decision-safe FAST): a ray with a decision inside a guard band stops where it stands and is evaluated by the listed
-//     kernel's rule (listed_one_ray), on the spot.
-// Every try is evaluated by the same device functions as everywhere else in the library: same bits as the batch kernels and as the
-// reference's loop order (tests/test_tile_gpu.py, tests/test_boundary_gpu.py).  rng: the ray's retry stream at its first draw.
-template <bool STRICT>
-__device__ __forceinline__ LaneRay kolb_wave_rays(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds, float4 s,
-                                                  Rng rng, bool active, bool guard)
+__device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have landed before any lane reads another lane's words
 {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- RAYTRACED, zoic.cpp:1850-1964, for the rays a wave holds: the TRIES of a ray side by side ------------------------------------
+// A resident wave is alone on its SIMD: what a call waits for is the longest CHAIN of dependent instructions, not their number (a
+// lone wave retires an instruction every ~10 cycles).  The reference's loop -- trace, and while the trace fails and tries <= 25 draw
+// the next lens sample -- is such a chain, up to 27 traces long; with one ray per lane all 64 rays of a wave waited for the
+// unluckiest (measured: 39 us for 64 samples of a double Gauss at f/2, 10 us for ONE sample), and a tile waits for its unluckiest
+// wave.  The tries of a ray are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1), so a wave holds
+// kKolbBatch = 16 rays and runs ROUNDS:
+//   * round 0: four lanes per ray evaluate tries 0 ... 3 side by side; the first success in try order wins (round 3's
+//     listed_short, kolb_listed_body.hpp): ~90 % of the rays are done;
+//   * every further round shares ALL 64 lanes among the rays still open (L = 64 / #open lanes each, up to 32): one or two open
+//     rays have their remaining 23 tries evaluated AT ONCE.  A batch is through after two rounds, three at the outside -- whatever
+//     its rays' try counts -- instead of up to seven;
+//   * ray state travels through the wave's LDS stage (the set-up constants, the stream at the next try, the next try's number), so
+//     a lane can take any ray in any round.
+// Per try: the sample's own lens point (try 0: x-only translation, zoic.cpp:1914) or a draw from the ray's stream; interface 0
+// first (most rejected tries die there), then the trace.  TIR bumps count for the tries before the winner only; try 26 hands out
+// its (partial) state with weight 0 (zoic.cpp:1927 / 1951); dead pixels (outside the image circle all 27 tries are one) and
+// retry-dead rays (dead_ray_end) end at try 0's failure, as in the batch kernels; GUARD (decision-safe FAST): a try with a decision
+// inside a guard band, at or before the winner, sends the ray to the listed kernel's rule (listed_one_ray), evaluated by one lane
+// once the rounds are over.  Every try is evaluated by the same device functions as everywhere else in the library: same bits as
+// the batch kernels and as the reference's loop order (tests/test_tile_gpu.py, tests/test_boundary_gpu.py).
+constexpr uint32_t kTileStageWords = 512;   // LDS stage per wave (THINLENS: 64 x 7 input dwords, then 64 x 8 record dwords)
+constexpr uint32_t kKolbBatch = 16;        // rays per wave pass
+// LDS stage of a wave (kTileStageWords dwords): [0, 128) the finished records, 8 dwords per ray (what the output stage reads);
+// [128, 448) the rays' state, 20 dwords each; [384, 496) the batch's input rows on arrival (dead before the state is written);
+// [448, 452) a round's outcome masks
+constexpr uint32_t kStageState = 128, kStageInput = 384, kStageMasks = 448;
+struct RayState {     // 20 dwords
+    float sx, sy, lensx, lensy;                         // the sample
+    uint32_t rng[4];                                    // the ray's retry stream at its first draw
+    float o0x, o0y, maxScale, translation, sn, cs;      // RaySetup
+    uint32_t flags;                                     // RaySetup::flags | dead pixel << 8 | lutEdge << 9 | try 0's sample finite << 10
+    uint32_t nextTry, tirTally, pad[3];
+};
+static_assert(sizeof(RayState) == 80 && kStageState + kKolbBatch * 20u <= kStageMasks && kStageMasks + 4u <= kTileStageWords, "stage layout");
+// (the state overlaps the input rows: they are in registers before the first state word is written)
+
+// Evaluates the rays 0 ... cnt-1 whose samples sit in `samples` (one per ray, lane r < cnt holds ray r's) and leaves their records
+// (ox oy oz dx dy dz weight flags, already negated, zoic.cpp:1960-1961) in stage[8 r ...].  rngOf(r): ray r's retry stream at its first
+// draw.  succ / vign / tir: the calling lane's counters.
+template <bool STRICT, bool GUARD, class RngOf>
+__device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds, float *stage,
+                                               float4 sample, uint32_t cnt, uint32_t lane, RngOf rngOf, uint32_t &succ, uint32_t &vign, uint32_t &tir)
+{
+    static_assert(!(STRICT && GUARD), "GUARD is a FAST mode");
     constexpr uint32_t kOut = static_cast<uint32_t>(kMaxTries) + 1u;   // tries of a ray that ran out (zoic.cpp:1927: tries <= 25)
-    LaneRay r;
-    const Rng rng0 = rng;
-    const RaySetup rs = setup_ray<STRICT>(T, lutLds, s.x, s.y);
-    r.lutMiss = rs.flags & 1u; r.tir = 0; r.tries = 0; r.vignetted = false;
-    bool unsure = guard && T.useLUT && rs.lutEdge;
-    const V3 o0{rs.o0x, rs.o0y, T.originShift};
-    V2 lens = lens_sample<STRICT>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
-    bool finiteSample = true;
-    if (rs.dead) {   // whatever finite point the sampler returns, the direction is (0 - o.x, 0 - o.y, dirZ) (kolb_pool_body.hpp)
-        const bool plainSample = (s.z >= 0.0f) & (s.z < 1.0f) & (s.w >= 0.0f) & (s.w < 1.0f) & !((s.z == 0.5f) & (s.w == 0.5f));
-        if (plainSample) lens = V2{0.0f, 0.0f};
-        finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
-    }
-    V3 d;
-    if (!T.useLUT) {                                           // zoic.cpp:1873-1877
-        d = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};
-    } else {                                                   // zoic.cpp:1913-1924: x-only translation on the first sample
-        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
-        lens.x += rs.translation;
-        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
-        d = V3{rx - o0.x, ry - o0.y, T.dirZ};
-    }
-    V3 o = o0;
-    const bool deadPixel = rs.dead && finiteSample, retryDead = (rs.flags & kRetryDeadBit) != 0u;
-    bool live = active && !unsure, endDead = false;
-    const auto clears_rear = [&](const V3 &dd, bool &near0) {
-        if constexpr (STRICT) {
-            near0 = false;
-            bool inRange;
-            bool p = interface0_clear_strict_lean(T, o0, dd, inRange);
-            if (__builtin_expect(!inRange, 0)) p = interface0_clear_strict(T, o0, dd);   // never seen: guarded roots
-            return p;
-        } else {
-            bool p;
-            if (guard) p = interface0_clear_fast<true>(T.fsurf[0], o0, dd, near0);
-            else p = interface0_clear_fast<false>(T.fsurf[0], o0, dd, near0);
-            return p;
+    RayState *state = reinterpret_cast<RayState *>(stage + kStageState);
+    float4 *records = reinterpret_cast<float4 *>(stage);
+    // ---- set-up, once per ray, by the lane that holds its sample ------------------------------------------------------------------
+    uint32_t listedMask = 0, deadEndMask = 0;   // wave-uniform: rays for the listed rule / retry-dead rays whose try 0 failed
+    {
+        const RaySetup rs = setup_ray<STRICT>(T, lutLds, sample.x, sample.y);
+        bool finiteSample = true;
+        if (rs.dead) {   // try 0 of a dead pixel shoots lens = (0, 0) whatever finite point the sampler returns (kolb_pool_body.hpp)
+            const bool plainSample = (sample.z >= 0.0f) & (sample.z < 1.0f) & (sample.w >= 0.0f) & (sample.w < 1.0f) & !((sample.z == 0.5f) & (sample.w == 0.5f));
+            if (!plainSample) { const V2 l = lens_sample<STRICT>(T, B, bokehLds, sample.z, sample.w); finiteSample = (fabsf(l.x) <= 3.0e38f) && (fabsf(l.y) <= 3.0e38f); }
         }
-    };
-    const auto draw = [&]() {                                   // zoic.cpp:1930-1943
-        const float u = rng_unit(xor128(rng));
-        const float v = rng_unit(xor128(rng));
-        ++r.tries;
-        d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-    };
-    // what a FAILED try does next: the shortcuts of a ray's first failure, out of tries, or the next draw.  Returns false when the ray ends.
-    const auto after_failure = [&](uint32_t tirTry) {
-        if (r.tries == 0u && deadPixel) { r.tir += kOut * tirTry; r.tries = kOut; return false; }   // 26 more identical failures
-        if (r.tries == 0u && retryDead) { endDead = true; return false; }
-        if (r.tries > static_cast<uint32_t>(kMaxTries)) return false;
-        draw();
-        return true;
-    };
-    while (__ballot(live) != 0ull) {
-        bool cand = false, searching = live;
-        while (__ballot(searching) != 0ull) {
-            if (searching) {
-                bool near0 = false;
-                const bool pass0 = clears_rear(d, near0);
-                if (near0) { unsure = true; live = false; searching = false; }
-                else if (pass0) { cand = true; searching = false; }
-                else if (!after_failure(0u)) { o = o0; live = false; searching = false; }   // a clip at interface 0 leaves (o, d) untouched
-            }
+        if (lane < cnt) {
+            RayState &q = state[lane];
+            q.sx = sample.x; q.sy = sample.y; q.lensx = sample.z; q.lensy = sample.w;
+            q.o0x = rs.o0x; q.o0y = rs.o0y; q.maxScale = rs.maxScale; q.translation = rs.translation; q.sn = rs.sn; q.cs = rs.cs;
+            q.flags = rs.flags | (rs.dead ? 0x100u : 0u) | (rs.lutEdge ? 0x200u : 0u) | (finiteSample ? 0x400u : 0u);
+            q.nextTry = 0u; q.tirTally = 0u;
+            const Rng r0 = rngOf(lane);
+            q.rng[0] = r0.x; q.rng[1] = r0.y; q.rng[2] = r0.z; q.rng[3] = r0.w;
         }
-        if (cand) {
-            V3 ot = o0, dt = d;
-            uint32_t tirTry = 0;
-            bool ok, near = false;
-            if constexpr (STRICT) ok = trace_lens_strict(T, ot, dt, tirTry);
-            else ok = trace_lens_fast_rolled(T, ot, dt, tirTry, guard ? &near : nullptr);
-            if (near) { unsure = true; live = false; }
-            else {
-                r.tir += tirTry;
-                if (ok) { o = ot; d = dt; live = false; }
-                else {
-                    if (!after_failure(tirTry)) { if (!endDead) { o = ot; d = dt; } live = false; }   // the reference's partial state (zoic.cpp:1951-1961)
+        if constexpr (GUARD) listedMask = static_cast<uint32_t>(__ballot(lane < cnt && T.useLUT && rs.lutEdge));   // the exit-pupil LUT's only discontinuity: the table's end
+    }
+    wave_lds_fence();
+    uint32_t open = (cnt >= 32u ? 0xffffffffu : ((1u << cnt) - 1u)) & ~listedMask;   // wave-uniform: rays with tries to run
+    while (open != 0u) {
+        // ---- this round's lanes: L per open ray (4 in round 0 of a full batch, up to 32 for the stragglers) -------------------------
+        const uint32_t nOpen = static_cast<uint32_t>(__builtin_popcount(open));
+        uint32_t L = 32u;
+        while (L * nOpen > 64u) L >>= 1;
+        const uint32_t pos = lane / L, t = lane & (L - 1u), blockBase = lane & ~(L - 1u);
+        // the pos-th open ray
+        uint32_t ray = pos;
+        if ((open & (open + 1u)) != 0u) {   // (holes in the mask: rays 0 ... nOpen-1 otherwise, round 0's case)
+            uint32_t m = open;
+            for (uint32_t i = 0; i < pos && m != 0u; ++i) m &= m - 1u;
+            ray = m ? static_cast<uint32_t>(__builtin_ctz(m)) : 0u;
+        }
+        const bool mine = pos < nOpen;
+        const RayState q = state[mine ? ray : static_cast<uint32_t>(__builtin_ctz(open))];
+        const uint32_t k = q.nextTry + t;               // this lane's try
+        const bool valid = mine && k <= kOut;
+        const bool deadPixel = (q.flags & 0x500u) == 0x500u, retryDead = (q.flags & kRetryDeadBit) != 0u;
+        const V3 o0{q.o0x, q.o0y, T.originShift};
+        V3 o = o0, d{0.0f, 0.0f, 1.0f};
+        bool ok = false, near = false;
+        uint32_t tirTry = 0;
+        if (valid) {
+            if (k == 0u) {                              // the sample's own lens point, zoic.cpp:1870-1924
+                V2 lens = lens_sample<STRICT>(T, B, bokehLds, q.lensx, q.lensy);
+                if (deadPixel) {
+                    const bool plainSample = (q.lensx >= 0.0f) & (q.lensx < 1.0f) & (q.lensy >= 0.0f) & (q.lensy < 1.0f) & !((q.lensx == 0.5f) & (q.lensy == 0.5f));
+                    if (plainSample) lens = V2{0.0f, 0.0f};
                 }
+                if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};   // zoic.cpp:1873-1877
+                else {                                  // zoic.cpp:1913-1924: x-only translation on the first sample
+                    lens.x *= q.maxScale; lens.y *= q.maxScale;
+                    lens.x += q.translation;
+                    const float rx = lens.x * q.cs - lens.y * q.sn, ry = lens.x * q.sn + lens.y * q.cs;
+                    d = V3{rx - o0.x, ry - o0.y, T.dirZ};
+                }
+            } else {                                    // try k draws 2 (k - 1), 2 (k - 1) + 1 of the ray's stream, zoic.cpp:1930-1943
+                Rng rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]};
+                for (uint32_t a = 1; a < k; ++a) { (void)xor128(rng); (void)xor128(rng); }
+                const float u = rng_unit(xor128(rng));
+                const float v = rng_unit(xor128(rng));
+                d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, u, v), q.o0x, q.o0y, q.maxScale, q.translation, q.sn, q.cs);
+            }
+            // interface 0 first (most rejected tries die there: a clip leaves (o, d) untouched and bumps nothing), then the trace
+            bool pass0;
+            if constexpr (STRICT) {
+                bool inRange;
+                pass0 = interface0_clear_strict_lean(T, o0, d, inRange);
+                if (__builtin_expect(!inRange, 0)) pass0 = interface0_clear_strict(T, o0, d);   // never seen: guarded roots
+            } else pass0 = interface0_clear_fast<GUARD>(T.fsurf[0], o0, d, near);
+            if (pass0 && !near) {
+                if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
+                else ok = trace_lens_fast_rolled(T, o, d, tirTry, GUARD ? &near : nullptr);
             }
         }
+        // ---- the ray's decision, in try order, by the L lanes of its block ---------------------------------------------------------------
+        const unsigned long long blockMask = (L >= 32u ? 0xffffffffull : ((1ull << L) - 1ull));
+        const uint32_t okB = static_cast<uint32_t>((__ballot(valid && ok && !near) >> blockBase) & blockMask);
+        const uint32_t nearB = static_cast<uint32_t>((__ballot(valid && near) >> blockBase) & blockMask);
+        const uint32_t tirB = static_cast<uint32_t>((__ballot(valid && tirTry != 0u) >> blockBase) & blockMask);
+        const uint32_t winner = okB ? static_cast<uint32_t>(__builtin_ctz(okB)) : 32u;         // lowest try that got through
+        const uint32_t firstNear = nearB ? static_cast<uint32_t>(__builtin_ctz(nearB)) : 32u;
+        const bool firstFailed = q.nextTry == 0u && (okB & 1u) == 0u && (nearB & 1u) == 0u;       // try 0 failed, decided
+        // 0 open still, 1 finished by lane `holder`, 2 listed, 3 retry-dead end
+        uint32_t outcome = 0, holder = 0, tirAdd = 0;
+        if (GUARD && firstNear < 32u && firstNear < winner) outcome = 2;          // too close to call before anything got through
+        else if (firstFailed && deadPixel) { outcome = 1; holder = 0; tirAdd = (1u + kOut) * (tirB & 1u); }    // 26 more identical failures
+        else if (firstFailed && retryDead) { outcome = 3; tirAdd = tirB & 1u; }    // tries 1 ... 26 die at interface 0
+        else if (winner < 32u) { outcome = 1; holder = winner; tirAdd = static_cast<uint32_t>(__builtin_popcount(tirB & ((1u << winner) - 1u))); }   // only the tries the reference ran
+        else {
+            tirAdd = static_cast<uint32_t>(__builtin_popcount(tirB));
+            if (q.nextTry + L > kOut) { outcome = 1; holder = kOut - q.nextTry; }   // try 26 failed as well: ITS partial state, weight 0
+        }
+        const uint32_t tally = q.tirTally + tirAdd;
+        if (mine && outcome == 1u && t == holder) {
+            const uint32_t tries = (firstFailed && deadPixel) ? kOut : k;
+            const bool vignetted = tries > static_cast<uint32_t>(kMaxTries);
+            float w = vignetted ? 0.0f : 1.0f;                                  // zoic.cpp:1951-1957 (try 26 that got through as well)
+            if (T.exposureOn) w *= T.exposureMul;                               // zoic.cpp:1981-1987
+            records[2u * ray] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);   // zoic.cpp:1960-1961
+            records[2u * ray + 1u] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | ((q.flags & 1u) << 6)));
+            tir += tally;
+            if (vignetted) ++vign; else ++succ;
+        }
+        if (mine && outcome == 0u && t == 0u) { state[ray].nextTry = q.nextTry + L; state[ray].tirTally = tally; }
+        if (mine && outcome == 3u && t == 0u) state[ray].tirTally = tally;
+        // the wave's view of who is still open: every block's first lane ORs its ray's bit into the round's masks
+        uint32_t *masks = reinterpret_cast<uint32_t *>(stage + kStageMasks);
+        if (lane < 3u) masks[lane] = 0u;
+        wave_lds_fence();
+        if (mine && t == 0u && (outcome == 0u || outcome >= 2u)) atomicOr(masks + (outcome == 0u ? 0 : outcome - 1u), 1u << ray);
+        wave_lds_fence();
+        const uint32_t stillOpen = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(masks[0]))), nowListed = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(masks[1]))),
+                       nowDeadEnd = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(masks[2])));
+        listedMask |= nowListed; deadEndMask |= nowDeadEnd;
+        open = stillOpen;
+        wave_lds_fence();
     }
-    if (endDead) {   // a retry-dead ray whose first try failed: tries 1 ... 26 die at interface 0; the state of the last draw
-        const DeadRayEnd e = dead_ray_end<STRICT>(T, B, bokehLds, rs, rng0);
-        r.o = e.o; r.d = e.d; r.w = e.w; r.tries = e.tries; r.vignetted = !e.nanDraw;
-        return r;
+    // ---- the rays the rounds could not finish: one lane each ---------------------------------------------------------------------------------
+    uint32_t later = listedMask | deadEndMask;
+    if (later != 0u) {
+        uint32_t m = later;
+        for (uint32_t i = 0; i < lane && m != 0u; ++i) m &= m - 1u;
+        if (lane < static_cast<uint32_t>(__builtin_popcount(later)) && m != 0u) {
+            const uint32_t ray = static_cast<uint32_t>(__builtin_ctz(m));
+            const RayState q = state[ray];
+            V3 o, d; float w; uint32_t tries, lutMiss = q.flags & 1u, tirRay; bool vignetted;
+            if ((deadEndMask >> ray) & 1u) {   // a retry-dead ray whose try 0 failed: the state of the last draw
+                RaySetup rs;
+                rs.o0x = q.o0x; rs.o0y = q.o0y; rs.maxScale = q.maxScale; rs.translation = q.translation; rs.sn = q.sn; rs.cs = q.cs; rs.flags = q.flags & (1u | kRetryDeadBit);
+                rs.dead = false; rs.lutEdge = false;
+                const DeadRayEnd e = dead_ray_end<STRICT>(T, B, bokehLds, rs, Rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]});
+                o = e.o; d = e.d; w = e.w; tries = e.tries; vignetted = !e.nanDraw; tirRay = q.tirTally;
+            } else {                           // a decision too close to call: the ray as the batch path's listed kernel evaluates it
+                const ListedRay l = listed_one_ray(T, B, lutLds, bokehLds, make_float4(q.sx, q.sy, q.lensx, q.lensy), Rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]});
+                o = l.o; d = l.d; w = l.w; tries = l.tries; lutMiss = l.lutMiss; tirRay = l.tir;
+                vignetted = tries > static_cast<uint32_t>(kMaxTries);
+            }
+            records[2u * ray] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);
+            records[2u * ray + 1u] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6)));
+            tir += tirRay;
+            if (vignetted) ++vign; else ++succ;
+        }
     }
-    if (unsure) {    // a decision too close to call: the ray is evaluated as the batch path's listed kernel does it (same rule, same bits)
-        const ListedRay q = listed_one_ray(T, B, lutLds, bokehLds, s, rng0);
-        r.o = q.o; r.d = q.d; r.w = q.w; r.tries = q.tries; r.lutMiss = q.lutMiss; r.tir = q.tir;
-        r.vignetted = r.tries > static_cast<uint32_t>(kMaxTries);
-        return r;
-    }
-    r.o = o; r.d = d;
-    r.vignetted = r.tries > static_cast<uint32_t>(kMaxTries);
-    r.w = r.vignetted ? 0.0f : 1.0f;                                    // zoic.cpp:1951-1957
-    if (T.exposureOn) r.w *= T.exposureMul;                             // zoic.cpp:1981-1987
-    return r;
+    wave_lds_fence();
 }
 
 // system scope (mapped host memory: never from / into a GPU cache) and agent scope (the job table: coherent across the XCDs' L2s)
@@ -200,6 +294,12 @@ __device__ __forceinline__ void load_dev4x3(const uint4 *p, uint4 &a, uint4 &b, 
                  "s_waitcnt vmcnt(0)" : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(p) : "memory");
     a = make_uint4(x.x, x.y, x.z, x.w); b = make_uint4(y.x, y.y, y.z, y.w); c = make_uint4(z.x, z.y, z.z, z.w);
 }
+__device__ __forceinline__ uint4 load_dev4(const uint4 *p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void store_dev4(uint4 *p, uint4 q)
 {
     const u32x4 v = {q.x, q.y, q.z, q.w};
@@ -210,24 +310,20 @@ __device__ __forceinline__ unsigned long long first_lane64(unsigned long long v)
 {
     return (static_cast<unsigned long long>(first_lane(static_cast<uint32_t>(v >> 32))) << 32) | first_lane(static_cast<uint32_t>(v));
 }
-__device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have landed before any lane reads another lane's words
-{
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-}
 
-constexpr uint32_t kTileStageWords = 512;   // per wave: 64 x 7 input dwords, then 64 x 8 record dwords
 
 // model: ZOIC_THINLENS 0 / ZOIC_RAYTRACED 1 (zoic_amd.h); mode: 0 STRICT, 1 FAST decision-safe, 2 FAST unchecked.
 // Waves 0 .. 63 of the launch are the SLOT waves (wave w owns slot w: a render thread never waits for another thread's ray --
 // one wave for all slots measured 8 us per call with one calling thread, 29 us with four), the waves behind them the tile WORKERS.
 // st->control (device memory): [0] exit flag (set by wave 0: stop request / 1 ms without a call / 50 ms of life), [1] waves that
 // have left, [2..3] wall-clock time of the last call any wave answered, [4..5] the work mask.
-__global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, const ThinTable Th, const BokehTables B, int model, int mode,
-                                                             char *mapped, MailDeviceState *st, DeviceCounters *counters, uint32_t ldsWords,
-                                                             uint32_t totalWaves)
+// One kernel per (lens model, precision mode): a resident wave is alone on its SIMD and waits for its instruction fetches like for
+// everything else -- with all six combinations in one kernel (138 KB of code against a 64 KB instruction cache) every pass missed.
+template <int MODEL, int MODE>
+__global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, const ThinTable Th, const BokehTables B, char *mapped,
+                                                             MailDeviceState *st, DeviceCounters *counters, uint32_t ldsWords, uint32_t totalWaves)
 {
+    constexpr uint32_t kRays = MODEL == 0 ? 64u : kKolbBatch;   // samples per batch of a tile: RAYTRACED spends at least four lanes on a ray (kolb_wave_rays)
     if (threadIdx.x < kLutEntries) {
         zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
         zoicDynLds[2 * threadIdx.x + 1] = T.lutCentroidX[threadIdx.x];
@@ -249,7 +345,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
     MailReply *replies = reinterpret_cast<MailReply *>(mapped + kMailRepliesOffset);
     uint32_t *tileFlags = reinterpret_cast<uint32_t *>(mapped + kMailTileFlagsOffset);   // [slot][batch]: the tile's sequence number when the batch's rows are complete
     uint32_t *control = st->control;
-    unsigned long long *workMask = reinterpret_cast<unsigned long long *>(control + 4);
+    unsigned long long *workMask = reinterpret_cast<unsigned long long *>(control + 4);   // control[4..7] = {mask lo, mask hi, turn, exit}: ONE load per worker poll
     volatile unsigned long long *lastCall = reinterpret_cast<volatile unsigned long long *>(control + 2);
     // All control flow below is wave-uniform (the polled words are broadcast to SGPRs).
     uint32_t mine = slotRole ? st->served[slot] : 0u;   // sequence number of the last call this slot answered
@@ -266,7 +362,12 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
     }
     const uint4 *myChunk = reinterpret_cast<const uint4 *>(requests + slot) + (lane < 3u ? lane : 3u);
     bool ownJob = false;        // slot role: this slot's tile still has batches to hand out
-    uint32_t idlePolls = 0;     // worker role
+    constexpr uint32_t kNoSlot = 0xffu;
+    const uint32_t workerWaves = totalWaves - kMailSlots;
+    uint32_t curSlot = kNoSlot, curPart = 0, partsTried = 0;   // the tile / ticket partition this wave draws from
+    bool scanMask = false, leaving = false;                    // worker role: look at the work mask; the exit flag has been seen
+    uint32_t idlePolls = 0;
+    unsigned long long lastWake = 0;                           // worker role: the wake word last acted on (a posted one is never 0)
     while (watched) {
         if (wall_clock64() - start > kMailHardLifeTicks) break;   // safety net (never seen): the host reports a tile that is never answered
         uint32_t work = 0;      // 1: one sample (slot role), 2: one 64-sample batch of a tile
@@ -286,7 +387,9 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             const unsigned long long now = wall_clock64();
             if (!fresh) {
                 if (slot == 0 && (stop != 0u || (now > lastSeen && now - lastSeen > kMailIdleTicks) || now - start > kMailLifeTicks)) {
-                    if (lane == 0) __hip_atomic_store(control, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // everybody out
+                    // everybody out: the slot waves read [0] with their request line, every worker its own wake line
+                    if (lane == 0) __hip_atomic_store(control, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    for (uint32_t i = lane; i < workerWaves; i += 64u) store_dev(&st->wake[i].word, (static_cast<unsigned long long>(static_cast<uint32_t>(now) | 1u) << 32) | 0x10000ull);
                     break;
                 }
                 if (leave != 0u) break;
@@ -307,42 +410,75 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 jobBase = (static_cast<unsigned long long>(lane_word(line.x, 2)) << 32) | lane_word(line.z, 1);
                 jobSeq = seq; jobSlot = slot; batch = 0;
                 if (jobN == 0u) continue;       // (the host never posts an empty tile)
-                work = 2;                       // batch 0 is this wave's, straight from the request: a tile of up to 64 samples involves nobody else
-                if (jobN > 64u) {
+                work = 2;                       // batch 0 is this wave's, straight from the request: a tile of one batch involves nobody else
+                if (jobN > kRays) {
                     // the rest is POSTED for the workers: descriptor (three 16-byte chunks, each ending in the tile's number, like a
-                    // request line), then the ticket counter at batch 1, then the slot's bit.  Whoever draws a ticket of generation
-                    // `seq` finds this descriptor; the ticket and the bit need no order between them (a worker that sees the bit first
-                    // draws a stale ticket and comes back).
+                    // request line), the ticket counters (partition 0 starts behind this wave's batch), the slot's bit; then as many
+                    // workers are woken as there are batches left, each with the partition it should start on.  Whoever draws a ticket
+                    // of generation `seq` finds this descriptor.
+                    const uint32_t batches = (jobN + kRays - 1u) / kRays;
+                    uint32_t parts = batches / 8u;   // about eight batches per counter: same-address atomics queue up (~0.1 us each across the XCDs)
+                    parts = parts < 1u ? 1u : (parts > kTileParts ? kTileParts : parts);
                     if (lane == 0) {
                         uint4 *J = reinterpret_cast<uint4 *>(st->jobs + slot);
                         store_dev4(J, make_uint4(lane_word(line.x, 0), lane_word(line.y, 0), jobN, seq));
                         store_dev4(J + 1, make_uint4(lane_word(line.x, 1), lane_word(line.y, 1), lane_word(line.z, 1), seq));
-                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), (jobN + 63u) >> 6, 0u, seq));
+                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts, seq));
+                        store_dev(&st->tickets[slot].partsLeft, parts);
+#ifdef ZOIC_TILE_TIMING
+                        store_dev(reinterpret_cast<unsigned long long *>(st->jobs + slot) + 6, static_cast<unsigned long long>(now));
+#endif
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                        store_dev(&st->tickets[slot].next, (static_cast<unsigned long long>(seq) << 32) | 1ull);
-                        (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    ownJob = true;
+                    if (lane < parts) store_dev(&st->tickets[slot].part[lane].next, (static_cast<unsigned long long>(seq) << 32) | (lane == 0u ? 1ull : 0ull));
+                    if (lane == 0) {
+                        (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // a woken worker finds the counters and the bit
+                    }
+                    if (workerWaves != 0u) {
+                        const uint32_t wakeN = batches - 1u < workerWaves ? batches - 1u : workerWaves;
+                        uint32_t at = 0;
+                        if (lane == 0) at = __hip_atomic_fetch_add(control + 8, wakeN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        at = first_lane(at);
+                        const unsigned long long tag = (static_cast<unsigned long long>(static_cast<uint32_t>(now) | 1u) << 32) | slot;
+                        for (uint32_t i = lane; i < wakeN; i += 64u) store_dev(&st->wake[(at + i) % workerWaves].word, tag | (static_cast<unsigned long long>(i % parts) << 8));
+                    }
+                    ownJob = true; curPart = 0; partsTried = 0;
                 }
             }
         }
-        if (work == 0u) {   // ---- draw a batch: a slot's wave from its own tile, a worker from any slot with its bit set
+        if (work == 0u) {   // ---- draw a batch: a slot's wave from its own tile, a worker from the tile it was woken for (then any posted one)
             if (slotRole) jobSlot = slot;
+            else if (curSlot != kNoSlot) jobSlot = curSlot;
             else {
-                const unsigned long long mask = first_lane64(load_dev(workMask));
-                if (mask == 0ull) {
-                    if ((++idlePolls & 7u) == 0u && first_lane(load_dev(control)) != 0u) break;   // exit flag: only with nothing left to hand out
-                    __builtin_amdgcn_s_sleep(4);   // the launch only lives while calls keep coming (1 ms): no point in polling slowly
+                if (scanMask) {   // nothing left of the tile this wave was on: any other posted tile?
+                    const unsigned long long mask = first_lane64(load_dev(workMask));
+                    if (mask != 0ull) {
+                        const uint32_t r = waveId & 63u;   // every worker starts its search at another slot
+                        const unsigned long long rot = r ? ((mask >> r) | (mask << (64u - r))) : mask;
+                        curSlot = (static_cast<uint32_t>(__builtin_ctzll(rot)) + r) & 63u;
+                        curPart = 0; partsTried = 0;   // (partition 0 exists whatever the tile's size)
+                        continue;
+                    }
+                    scanMask = false;
+                    if (leaving) break;   // exit flag: only with nothing left to hand out
+                }
+                const unsigned long long wk = first_lane64(load_dev(&st->wake[waveId - kMailSlots].word));
+                if (wk == lastWake) {
+                    // (a hint written behind the exit word hides it: every 16th idle poll looks at the launch's exit flag itself)
+                    if ((++idlePolls & 15u) == 0u && first_lane(load_dev(control)) != 0u) { leaving = true; scanMask = true; continue; }
+                    __builtin_amdgcn_s_sleep(6);   // ~0.15 us: every worker polls its own line, but a thousand of them add up on the fabric
                     continue;
                 }
-                const uint32_t r = waveId & 63u;   // every worker starts its search at another slot
-                const unsigned long long rot = r ? ((mask >> r) | (mask << (64u - r))) : mask;
-                jobSlot = (static_cast<uint32_t>(__builtin_ctzll(rot)) + r) & 63u;
+                lastWake = wk;
+                if ((wk >> 16) & 1ull) { leaving = true; scanMask = true; continue; }
+                curSlot = static_cast<uint32_t>(wk) & 63u; curPart = static_cast<uint32_t>(wk >> 8) & (kTileParts - 1u); partsTried = 0;
+                continue;
             }
             // the ticket and -- speculatively, in the same round trip -- the descriptor
             const uint4 *J = reinterpret_cast<const uint4 *>(st->jobs + jobSlot);
             unsigned long long t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(&st->tickets[jobSlot].next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) t = __hip_atomic_fetch_add(&st->tickets[jobSlot].part[curPart].next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint4 c0, c1, c2;
             load_dev4x3(J, c0, c1, c2);
             t = first_lane64(t);
@@ -352,83 +488,110 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 load_dev4x3(J, c0, c1, c2);
             }
-            batch = static_cast<uint32_t>(t);
-            const uint32_t batches = first_lane(c2.y);
-            if (first_lane(c0.w) != gen || first_lane(c1.w) != gen || first_lane(c2.w) != gen || batch >= batches) {   // nothing left of that tile
-                if (slotRole) ownJob = false; else __builtin_amdgcn_s_sleep(1);
+            const uint32_t batches = first_lane(c2.y), parts = first_lane(c2.z);
+            const bool sameTile = first_lane(c0.w) == gen && first_lane(c1.w) == gen && first_lane(c2.w) == gen;
+            const uint32_t per = sameTile ? (batches + parts - 1u) / parts : 1u;
+            const uint32_t lo = curPart * per, hi = lo + per < batches ? lo + per : batches;   // the partition's batches
+            batch = lo + static_cast<uint32_t>(t);
+            if (!sameTile || curPart >= parts || batch >= hi) {
+                // a stale ticket (the tile has been handed out: its counters belong to nobody, or to the next tile -- whose descriptor
+                // then differs) or a partition that is empty: on to the next partition; after all of them, the tile is done with
+                // (a look at the work mask first: once the tile's bit is gone every partition is empty -- one load instead of an atomic per
+                // remaining partition from each of the tile's workers)
+                ++partsTried;
+                const bool gone = !sameTile || partsTried >= parts || ((first_lane64(load_dev(workMask)) >> jobSlot) & 1ull) == 0ull;
+                if (gone) {
+                    if (slotRole) ownJob = false; else { curSlot = kNoSlot; scanMask = true; }
+                } else curPart = (curPart + 1u) % parts;
                 continue;
             }
-            // the LAST valid ticket clears the slot's bit: the tile cannot complete (and the slot post another) before this wave is done
-            if (batch + 1u == batches && lane == 0) (void)__hip_atomic_fetch_and(workMask, ~(1ull << jobSlot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the LAST batch of a partition counts the partition down, the last partition clears the slot's bit: both by waves that hold
+            // a valid batch, so the tile cannot complete (and the slot post another) before they are done
+            if (batch + 1u == hi && lane == 0) {
+                if (__hip_atomic_fetch_sub(&st->tickets[jobSlot].partsLeft, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
+                    (void)__hip_atomic_fetch_and(workMask, ~(1ull << jobSlot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             jobSeq = gen;
             jobN = first_lane(c0.z);
             jobIn = (static_cast<unsigned long long>(first_lane(c0.y)) << 32) | first_lane(c0.x);
             jobOut = (static_cast<unsigned long long>(first_lane(c1.y)) << 32) | first_lane(c1.x);
             jobBase = (static_cast<unsigned long long>(first_lane(c2.x)) << 32) | first_lane(c1.z);
-            idlePolls = 0;
             work = 2;
         }
+#ifdef ZOIC_TILE_TIMING
+        const unsigned long long tt0 = wall_clock64();
+#endif
 
         // ---- the pass's samples: the slot's one sample in lane 0, or 64 consecutive rows of the tile --------------------------
-        bool active = lane == 0;
+        // (lane r holds ray r's sample; RAYTRACED shares the wave's lanes among the rays' tries afterwards, kolb_wave_rays)
+        constexpr uint32_t kIn = MODEL == 0 ? 0u : kStageInput;   // where the input rows land in the wave's stage
+        bool active = lane == 0u;
         uint32_t first = 0, cnt = 1;
-        unsigned long long rayIndex = 0;
+        unsigned long long rayBase = 0;
         if (work == 2u) {
-            first = batch * 64u;
-            cnt = jobN - first < 64u ? jobN - first : 64u;
+            first = batch * kRays;
+            cnt = jobN - first < kRays ? jobN - first : kRays;
             // AtCameraInput rows are 7 dwords (sx sy dsx dsy lensx lensy relative_time): lane l fetches dword k * 64 + l of the batch's
             // 7 * cnt -- whole 256-byte runs per instruction across PCIe -- and picks its row out of LDS
             const uint32_t *src = reinterpret_cast<const uint32_t *>(jobIn) + static_cast<size_t>(first) * 7u;
             const uint32_t total = cnt * 7u;
-            uint32_t w7[7];
+            constexpr uint32_t kLoads = (kRays * 7u + 63u) / 64u;
+            uint32_t w7[kLoads];
 #pragma unroll
-            for (uint32_t k = 0; k < 7u; ++k) { const uint32_t j = k * 64u + lane; w7[k] = load_sys(src + (j < total ? j : total - 1u)); }
+            for (uint32_t k = 0; k < kLoads; ++k) { const uint32_t j = k * 64u + lane; w7[k] = load_sys(src + (j < total ? j : total - 1u)); }
 #pragma unroll
-            for (uint32_t k = 0; k < 7u; ++k) stage[k * 64u + lane] = __builtin_bit_cast(float, w7[k]);
+            for (uint32_t k = 0; k < kLoads; ++k) { const uint32_t j = k * 64u + lane; if (j < kRays * 7u) stage[kIn + j] = __builtin_bit_cast(float, w7[k]); }
             wave_lds_fence();
             active = lane < cnt;
-            const uint32_t row = (active ? lane : 0u) * 7u;
+            const uint32_t row = kIn + (active ? lane : 0u) * 7u;
             s = make_float4(stage[row], stage[row + 1u], stage[row + 4u], stage[row + 5u]);
             wave_lds_fence();   // ... before the records go into the same words
-            rayIndex = jobBase + first + lane;
+            rayBase = jobBase + first;
         }
 
+#ifdef ZOIC_TILE_TIMING
+        const unsigned long long tt1 = wall_clock64();
+#endif
         // ---- the rays (ONE site for both kinds of work) -------------------------------------------------------------------------
-        V3 o{0.0f, 0.0f, 0.0f}, d{0.0f, 0.0f, 0.0f};
-        float w = 0.0f;
-        uint32_t tries = 0, lutMiss = 0;
-        if (model == 0) {   // THINLENS, zoic.cpp:1771-1846
+        if constexpr (MODEL == 0) {   // THINLENS, zoic.cpp:1771-1846: one ray per lane
+            V3 o{0.0f, 0.0f, 0.0f}, d{0.0f, 0.0f, 0.0f};
+            float w = 0.0f;
+            uint32_t tries = 0;
             if (active) {
                 ThinRay r;
                 if (work == 2u) {   // a tile's ray = the batch kernels' ray: its own stream, seeded at its first redraw; FAST where they run FAST
                     Rng q{1u, 2u, 3u, 4u};
-                    if (mode != 0 && Th.useDof && Th.ovDistance > 0.0f) r = thin_ray_fast_vignet(Th, B, bokehLds, s, q, [&] { q = rng_for_ray(Th.seed, rayIndex); });
-                    else r = thin_ray_strict(Th, B, bokehLds, s, q, [&] { q = rng_for_ray(Th.seed, rayIndex); });
+                    if (MODE != 0 && Th.useDof && Th.ovDistance > 0.0f) r = thin_ray_fast_vignet(Th, B, bokehLds, s, q, [&] { q = rng_for_ray(Th.seed, rayBase + lane); });
+                    else r = thin_ray_strict(Th, B, bokehLds, s, q, [&] { q = rng_for_ray(Th.seed, rayBase + lane); });
                 } else {            // one sample: the calling tid's stream, the reference's arithmetic in every precision mode
                     Rng q = rng;
                     r = thin_ray_strict(Th, B, bokehLds, s, q, [] {});
                 }
                 o = r.origin; d = r.dir; w = r.w; tries = r.tries;
                 if (Th.useDof) { if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ; }
+                float4 *rec = reinterpret_cast<float4 *>(stage) + 2u * lane;
+                rec[0] = make_float4(o.x, o.y, o.z, d.x);
+                rec[1] = make_float4(d.y, d.z, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1)));
             }
-        } else {            // RAYTRACED: every lane takes part in the wave's rounds (kolb_wave_rays); idle lanes ride along
-            if (work == 2u) rng = rng_for_ray(T.seed, rayIndex);
-            LaneRay r;
-            if (mode == 0) r = kolb_wave_rays<true>(T, B, lutLds, bokehLds, s, rng, active, false);
-            else r = kolb_wave_rays<false>(T, B, lutLds, bokehLds, s, rng, active, mode == 1);
-            o = V3{r.o.x * -1.0f, r.o.y * -1.0f, r.o.z * -1.0f}; d = V3{r.d.x * -1.0f, r.d.y * -1.0f, r.d.z * -1.0f};   // zoic.cpp:1960-1961
-            w = r.w; tries = r.tries; lutMiss = r.lutMiss;
-            if (active) { tir += r.tir; if (r.vignetted) ++vign; else ++succ; }
+            wave_lds_fence();
+        } else {                      // RAYTRACED: the tries of a ray side by side (kolb_wave_rays); every lane takes part in the wave's rounds
+            const bool tileWork = work == 2u;
+            const uint32_t seed = T.seed;
+            const auto rngOf = [&](uint32_t ray) { return tileWork ? rng_for_ray(seed, rayBase + ray) : rng; };
+            kolb_wave_rays<MODE == 0, MODE == 1>(T, B, lutLds, bokehLds, stage, s, cnt, lane, rngOf, succ, vign, tir);
         }
-        const uint32_t flags = (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6);
 
+#ifdef ZOIC_TILE_TIMING
+        const unsigned long long tt2 = wall_clock64();
+#endif
         // ---- the answer -----------------------------------------------------------------------------------------------------------
         if (work == 1u) {
-            if (lane == 0) {
+            if (lane == 0) {   // the one ray's record: ox oy oz dx | dy dz w flags
+                const float4 r0 = reinterpret_cast<const float4 *>(stage)[0], r1 = reinterpret_cast<const float4 *>(stage)[1];
                 uint4 *a = reinterpret_cast<uint4 *>(replies + slot);
-                store_uncached(a, make_uint4(__builtin_bit_cast(uint32_t, o.x), __builtin_bit_cast(uint32_t, o.y), __builtin_bit_cast(uint32_t, o.z), seq));
-                store_uncached(a + 1, make_uint4(__builtin_bit_cast(uint32_t, d.x), __builtin_bit_cast(uint32_t, d.y), __builtin_bit_cast(uint32_t, d.z), seq));
-                store_uncached(a + 2, make_uint4(__builtin_bit_cast(uint32_t, w), flags, 0u, seq));
+                store_uncached(a, make_uint4(__builtin_bit_cast(uint32_t, r0.x), __builtin_bit_cast(uint32_t, r0.y), __builtin_bit_cast(uint32_t, r0.z), seq));
+                store_uncached(a + 1, make_uint4(__builtin_bit_cast(uint32_t, r0.w), __builtin_bit_cast(uint32_t, r1.x), __builtin_bit_cast(uint32_t, r1.y), seq));
+                store_uncached(a + 2, make_uint4(__builtin_bit_cast(uint32_t, r1.z), __builtin_bit_cast(uint32_t, r1.w), 0u, seq));
             }
             continue;
         }
@@ -436,14 +599,10 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         // writes them (kernels.hip expand_outputs_kernel): origin / dir, dOdy = origin and dDdy = dir for retried rays
         // (zoic.cpp:1974-1977), weight r = g = b, zeros in what camera_create_ray leaves alone.  One lane per output FLOAT.
         {
-            float4 *rec = reinterpret_cast<float4 *>(stage) + 2u * lane;
-            rec[0] = make_float4(o.x, o.y, o.z, d.x);
-            rec[1] = make_float4(d.y, d.z, w, __builtin_bit_cast(float, flags));
-            wave_lds_fence();
             uint32_t *dst = reinterpret_cast<uint32_t *>(jobOut) + static_cast<size_t>(first) * 21u;
             const uint32_t total = cnt * 21u;
 #pragma unroll
-            for (uint32_t k = 0; k < 21u; ++k) {
+            for (uint32_t k = 0; k < (kRays * 21u + 63u) / 64u; ++k) {
                 const uint32_t j = k * 64u + lane;
                 if (j < total) {
                     const uint32_t ray = j / 21u, f = j - ray * 21u;
@@ -462,7 +621,18 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         // the batch's rows are released at system scope; then its flag says so to the render thread (which waits for every flag of
         // its tile: no counter, no last wave, nobody waits for anybody on the device)
         __threadfence_system();
-        if (lane == 0) store_sys(tileFlags + jobSlot * kTileMaxBatches + batch, jobSeq);
+        if (lane == 0) store_sys(tileFlags + static_cast<size_t>(jobSlot) * kTileMaxBatches + batch, jobSeq);
+#ifdef ZOIC_TILE_TIMING
+        if (lane == 0) {
+            const unsigned long long tt3 = wall_clock64();
+            const int o = slotRole ? 0 : 4;
+            if (!slotRole) {
+                const unsigned long long tp = load_dev(reinterpret_cast<unsigned long long *>(st->jobs + jobSlot) + 6);
+                atomicAdd(&st->timing[8], tt0 - tp); atomicMax(&st->timing[9], tt0 - tp); atomicAdd(&st->timing[10], tt3 - tp); atomicMax(&st->timing[11], tt3 - tp);
+            }
+            atomicAdd(&st->timing[o], 1ull); atomicAdd(&st->timing[o + 1], tt1 - tt0); atomicAdd(&st->timing[o + 2], tt2 - tt1); atomicAdd(&st->timing[o + 3], tt3 - tt2);
+        }
+#endif
     }
     for (int off = 32; off > 0; off >>= 1) { succ += __shfl_xor(succ, off, 64); vign += __shfl_xor(vign, off, 64); tir += __shfl_xor(tir, off, 64); }
     if (lane == 0) {
@@ -477,6 +647,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         __threadfence_system();
         if (atomicAdd(control + 1, 1u) == totalWaves - 1u) {   // the last wave out resets the control block and clears `alive`
             control[1] = 0u;
+            for (uint32_t i = 0; i < workerWaves; ++i) st->wake[i].word = 0ull;   // the exit words: the next launch's workers start on clean lines
             __hip_atomic_store(control, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
             store_uncached(reinterpret_cast<uint4 *>(header) + 1, make_uint4(0u, 0u, 0u, 0u));   // the last thing this launch does
@@ -492,9 +663,16 @@ int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTabl
     const bool image = (model == 0 ? thin.useImage : kolb.useImage) != 0;
     const uint32_t ldsWords = (image && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
     const uint32_t groups = kMailSlotGroups + workerGroups;
-    hipLaunchKernelGGL(mailbox_kernel, dim3(groups), dim3(kMailBlock), (kLutLdsWords + ldsWords + (kMailBlock / 64u) * kTileStageWords) * sizeof(float),
-                       static_cast<hipStream_t>(stream), kolb, thin, bokeh, model, mode, static_cast<char *>(d_mapped), d_state, d_counters, ldsWords,
-                       groups * (kMailBlock / 64u));
+    const size_t lds = (kLutLdsWords + ldsWords + (kMailBlock / 64u) * kTileStageWords) * sizeof(float);
+#define ZOIC_LAUNCH_MAILBOX(MODEL_, MODE_)                                                                                       \
+    hipLaunchKernelGGL((mailbox_kernel<MODEL_, MODE_>), dim3(groups), dim3(kMailBlock), lds, static_cast<hipStream_t>(stream), kolb, thin, bokeh, \
+                       static_cast<char *>(d_mapped), d_state, d_counters, ldsWords, groups * (kMailBlock / 64u))
+    if (model == 0) {   // (THINLENS: MODE only tells the vignetting loop's arithmetic apart)
+        if (mode == 0) ZOIC_LAUNCH_MAILBOX(0, 0); else ZOIC_LAUNCH_MAILBOX(0, 1);
+    } else if (mode == 0) ZOIC_LAUNCH_MAILBOX(1, 0);
+    else if (mode == 1) ZOIC_LAUNCH_MAILBOX(1, 1);
+    else ZOIC_LAUNCH_MAILBOX(1, 2);
+#undef ZOIC_LAUNCH_MAILBOX
     return static_cast<int>(hipGetLastError());
 }
 

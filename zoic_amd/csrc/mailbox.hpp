@@ -10,7 +10,7 @@ namespace zoic {
 constexpr uint32_t kMailSlots = 64;                       // one slot per SLOT wave of the resident launch; tid -> slot tid % 64
 constexpr uint32_t kMailBlock = 256;                      // 4 waves per workgroup: 16 slot workgroups, then the tile workers'
 constexpr uint32_t kMailSlotGroups = kMailSlots * 64u / kMailBlock;
-constexpr uint32_t kTileWorkerGroups = 64;                // default number of worker workgroups (x 4 waves) once a tile has been submitted
+constexpr uint32_t kTileWorkerGroups = 256;               // default number of worker workgroups (x 4 waves) once a tile has been submitted
 constexpr uint32_t kTileMaxSamples = 65536;               // samples per tile request (ZOIC_TILE_MAX_SAMPLES)
 constexpr unsigned long long kMailIdleTicks = 100000;     // 1 ms of the 100 MHz wall clock without a call: the kernel retires
 constexpr unsigned long long kMailLifeTicks = 5000000;    // 50 ms: ... and in any case, so that a device-wide synchronise ends
@@ -48,28 +48,36 @@ static_assert(sizeof(MailRequest) == 64 && sizeof(MailTileRequest) == 64 && size
 // byte offsets into the mapped allocation
 // (tile flags: one word per 64-sample batch of a slot's tile -- the tile's sequence number once the batch's rows are complete, written
 // by the wave that made them behind a system-scope release; the render thread waits for all of its tile's)
-constexpr uint32_t kTileMaxBatches = kTileMaxSamples / 64u;
+constexpr uint32_t kTileRaysRaytraced = 16, kTileRaysThin = 64;   // samples per batch of a tile (mailbox.hip: RAYTRACED spends four lanes on a ray)
+constexpr uint32_t kTileMaxBatches = kTileMaxSamples / kTileRaysRaytraced;
 constexpr size_t kMailRequestsOffset = 64, kMailRepliesOffset = kMailRequestsOffset + 64 * kMailSlots,
                  kMailTileFlagsOffset = kMailRepliesOffset + 64 * kMailSlots, kMailBytes = kMailTileFlagsOffset + 4u * kTileMaxBatches * kMailSlots;
 
 // Device-memory state of the resident launch (survives its retirements): what a slot has answered, the launch's control block,
 // and the tile jobs the slot waves post for the workers.
+constexpr uint32_t kTileParts = 32;           // ticket partitions of a tile: same-address atomics are served one at a time
+constexpr uint32_t kTileMaxWorkerWaves = 1024;   // wake lines (kTileWorkerGroups x 4 waves by default; ZOIC_TILE_WORKER_GROUPS <= 256)
 struct alignas(64) TileJob {                  // three 16-byte chunks, each ending in the tile's sequence number (like a request line):
     uint32_t inLo, inHi, n, seq0;             // written by the slot's wave, read -- in the same round trip as the ticket -- by whoever
     uint32_t outLo, outHi, baseLo, seq1;      // draws one; a descriptor whose three numbers equal the ticket's generation is that tile's
-    uint32_t baseHi, batches, pad, seq2;
-    uint32_t fill[4];
+    uint32_t baseHi, batches, parts, seq2;    // parts: ticket partitions in use (1 ... kTileParts); partition p hands out batches
+    uint32_t fill[4];                         //        [p * per, min((p + 1) * per, batches)), per = ceil(batches / parts)
 };
-struct alignas(64) TileTicket {               // (generation << 32) | next batch: one atomicAdd hands a batch out
-    unsigned long long next;
-    uint32_t pad[14];
-};
+struct alignas(64) TileCounter { unsigned long long next; uint32_t pad[14]; };   // (generation << 32) | next batch of the partition
+struct alignas(64) TileTickets {
+    TileCounter part[kTileParts];             // one atomicAdd hands a batch out
+    uint32_t partsLeft, pad[15];              // partitions with batches left: the wave that draws a partition's last batch counts it down,
+};                                            // the one that counts the last partition clears the slot's bit in the work mask
+struct alignas(64) TileWake { unsigned long long word; uint32_t pad[14]; };   // per WORKER wave: (changing number << 32) | exit << 16 | partition << 8 | slot (6 bits)
 struct MailDeviceState {
     uint32_t served[kMailSlots];              // sequence number of the last call each slot answered
     alignas(64) uint32_t control[16];         // [0] exit flag, [1] waves that have left, [2..3] wall-clock time of the last call,
-                                              // [4..5] 64-bit mask of the slots whose tile still has batches to hand out
+                                              // [4..5] 64-bit mask of the slots whose tile still has batches to hand out,
+                                              // [8] next worker wave to wake (rotates: tiles of different slots wake different waves)
     TileJob jobs[kMailSlots];
-    TileTicket tickets[kMailSlots];
+    TileTickets tickets[kMailSlots];
+    TileWake wake[kTileMaxWorkerWaves];
+    unsigned long long timing[16];            // -DZOIC_TILE_TIMING builds only: 10 ns ticks per region of a batch, summed over all waves (tools/)
 };
 
 int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, void *d_mapped,
