@@ -63,7 +63,10 @@ NOTES = {
               "identical history and weight != 0; north-star tolerance 1e-5",
     "sharded_frame": "one frame in ray-index slabs; on one GPU there is nothing to gather and a slab is ONE launch",
     "host_path": "zoic_create_rays_host / _arnold end to end over PCIe, 16.8 M samples; per_sample = zoic_camera_create_ray "
-                 "(resident mailbox kernel) timed by tools/native/sample_latency.c",
+                 "(resident mailbox kernel) timed by tools/native/sample_latency.c; tile = zoic_tile_submit + _wait (resident tile server: no "
+                 "launch) from render threads with a page-locked tile each, tools/native/tile_latency.c: aggregate Mrays/s over the wall clock, "
+                 "p50 / p99 us per call; pcie_floor_us = 112 B/sample (28 in, 84 out) at 55 GB/s; launch_* = zoic_create_rays_arnold on "
+                 "page-locked arrays, the call a tile replaces",
     "cpu_baseline": "the oracle on this box's host cores, page-touched buffers, >= 3 repetitions of >= 3 s; one_thread = the "
                     "sequential process-global xor128 (the configuration the reference is validated in); scaling_efficiency = all / "
                     "(one x cores); BASELINE.md: the true reference does 0.6-1.0 Mrays/s per thread",
@@ -409,7 +412,15 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
         into_root = payload * (n_total - (frame.slabs[0][1] - frame.slabs[0][0]))
         ingest = into_root * steps / t_gather / 1e9
         ent.update(with_gather=round(n_total * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3), chunk_mb=frame.chunk_bytes >> 20,
-                   root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((world - 1) * XGMI_LINK_GBS), 3))
+                   root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((world - 1) * XGMI_LINK_GBS), 3), root_bytes=into_root)
+        # the gather with only the rays of weight != 0 on the wire (ShardedFrame(sparse=True): counts first, then bits + rows)
+        try:
+            frame.sparse = True
+            t_sparse = timed(True)
+            ent.update(with_sparse_gather=round(n_total * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3), root_bytes_sparse=int(frame.root_bytes))
+        except Exception as e:  # noqa: BLE001
+            ent["sparse_failed"] = str(e)[:120]
+        frame.sparse = False
         # rank 0 holds the gathered frame: a peer's chunk must equal what this GPU computes for the same global rays
         full = frame.run(gather=True)
         torch.cuda.synchronize()
@@ -427,7 +438,7 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
 def single_process_frame_entry(torch, cfg_name, precision, devices, steps, warmup, ent=None):
     """The same frame through the C-ABI's zoic_frame_* (csrc/frame.cpp): THIS process alone drives every device -- the form a
     C++ plug-in can call (the reference is one process).  Gather = hipMemcpyPeerAsync of the 28-byte payload to devices[0]."""
-    from zoic_amd import FRAME_PAYLOAD, PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, ZoicFrame
+    from zoic_amd import FRAME_PAYLOAD, FRAME_PAYLOAD_SPARSE, PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, ZoicFrame
     from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_count
     cfg = CONFIGS[cfg_name]
     n = ray_count(cfg_name)
@@ -458,7 +469,14 @@ def single_process_frame_entry(torch, cfg_name, precision, devices, steps, warmu
         ent.update(compute_only=round(n * steps / t_local / 1e6, 1), compute_ms=round(t_local / steps * 1e3, 3))
         t_gather = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD))
         into_root = 28 * (n - (frame.slab(n, 0)[1] - frame.slab(n, 0)[0]))
-        ent.update(with_gather=round(n * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3))
+        ent.update(with_gather=round(n * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3),
+                   root_bytes=sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices))),
+                   peer_access=[int(frame.lane_info(i)["peer_access_to_root"] and frame.lane_info(i)["peer_access_from_root"]) for i in range(len(devices))])
+        # the same gather with only the rays of weight != 0 on the wire (ZOIC_FRAME_PAYLOAD_SPARSE)
+        t_sparse = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD_SPARSE))
+        ent.update(with_sparse_gather=round(n * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3),
+                   root_bytes_sparse=sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices))))
+        t_gather = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD))   # (the dense rows again: what the bit-identity check below reads)
         if len(set(devices)) > 1:   # (a device listed twice copies to itself: no link involved)
             ingest = into_root * steps / t_gather / 1e9
             ent.update(root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((len(devices) - 1) * XGMI_LINK_GBS), 3))
@@ -492,6 +510,29 @@ def per_sample_latency():
             out = subprocess.run([exe, lens, str(threads), "40000", str(precision), "1"], capture_output=True, text=True, timeout=120)
             j = json.loads(out.stdout.strip().splitlines()[-1])
             res[key] = {"median_us": j["median_us"], "p99_us": j["p99_us"], "calls_per_s": round(j["calls_per_s"])}
+        except Exception as e:  # noqa: BLE001
+            res[key] = {"error": repr(e)[:80]}
+    return res
+
+
+def tile_server_entry():
+    """Bucket-sized calls through the resident tile server (zoic_tile_*, csrc/mailbox.hip) as render threads see them
+    (tools/native/tile_latency.c, built by __graft_entry__.build()): 16 threads x 64 x 64 x 16 spp tiles and one thread's 4096-sample
+    tile, FAST, double Gauss at f/2 without the image; beside them the launch-based call they replace (zoic_create_rays_arnold on
+    page-locked arrays) on the same shapes."""
+    exe = os.path.join(ROOT, "tools", "native", "tile_latency")
+    lens = os.path.join(ROOT, "zoic_amd", "lenses", "double_gauss_f2.0.dat")
+    if not os.path.exists(exe):
+        return {"error": "tools/native/tile_latency not built"}
+    res = {}
+    legs = (("tile_16_threads_x_65536", ["16", "65536", "60", "1", "1", "0"]), ("tile_1_thread_x_4096", ["1", "4096", "1000", "1", "1", "0"]),
+            ("tile_1_thread_x_256", ["1", "256", "1000", "1", "1", "0"]), ("tile_thin_lens_1_thread_x_4096", ["1", "4096", "1000", "1", "0", "0"]),
+            ("launch_16_threads_x_65536", ["16", "65536", "30", "1", "1", "3"]), ("launch_1_thread_x_4096", ["1", "4096", "300", "1", "1", "3"]))
+    for key, a in legs:
+        try:
+            out = subprocess.run([exe, lens] + a, capture_output=True, text=True, timeout=180)
+            j = json.loads(out.stdout.strip().splitlines()[-1])
+            res[key] = {"mrays_s": j["mrays_s"], "p50_us": j["p50_us"], "p99_us": j["p99_us"], "pcie_floor_us": j["pcie_floor_us"]}
         except Exception as e:  # noqa: BLE001
             res[key] = {"error": repr(e)[:80]}
     return res
@@ -654,6 +695,7 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and not args.no_host_path and world == 1:
         line["host_path"]["per_sample"] = per_sample_latency()
+        line["host_path"]["tile"] = tile_server_entry()
 
     if not args.no_configs and world == 1:
         ents = []

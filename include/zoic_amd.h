@@ -284,8 +284,17 @@ zoic_status zoic_generate_samples_device(zoic_camera *cam, uint64_t n, uint64_t 
 typedef struct zoic_frame zoic_frame;
 typedef enum zoic_frame_layout {
     ZOIC_FRAME_RECORDS = 0, /* n zoic_ray records (32 B/ray, flag word included) */
-    ZOIC_FRAME_PAYLOAD = 1  /* n rows of 7 f32: ox oy oz dx dy dz weight (28 B/ray, SURVEY 8e's gather; the flag word stays on
+    ZOIC_FRAME_PAYLOAD = 1, /* n rows of 7 f32: ox oy oz dx dy dz weight (28 B/ray, SURVEY 8e's gather; the flag word stays on
                                the device that traced the ray) */
+    ZOIC_FRAME_PAYLOAD_SPARSE = 2 /* the same n rows on the root, but only the rays with weight != 0 are TRANSPORTED: a peer's chunk
+                               travels as a 256-bit live mask per 256-ray tile + the compacted rows of its live rays and is expanded
+                               on the root.  Rows of weight-0 rays arrive as seven zeros: their origin / direction (the reference's
+                               partial state of the last try, zoic.cpp:1951-1961) and their try counts are NOT transported -- they stay
+                               in the tracing device's records.  Rows of live rays are bit-identical to ZOIC_FRAME_PAYLOAD's.  A wide-open
+                               PETZVAL frame (79 % weight 0) moves 4.5x fewer bytes into the root.  The size of a chunk is only known on
+                               the device: zoic_frame_render_device reads one 4-byte count per chunk back before it queues the copy, so
+                               with this layout the call returns when the last chunk has been TRACED (copies and expansions may still
+                               be in flight behind root_stream); zoic_frame_get_lane_info::bytes_to_root says what moved */
 } zoic_frame_layout;
 
 /* [begin, end) of device i's slab of an n-sample call over n_devices devices.  Pure arithmetic, callable without a device. */

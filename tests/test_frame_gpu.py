@@ -123,3 +123,46 @@ def test_frame_entry_points_from_plain_c(gpu):
     r = subprocess.run([exe, os.path.join(root, "zoic_amd", "lenses", "tessar_f2.8.dat")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert '"identical": 1' in r.stdout and '"counters_ok": 1' in r.stdout
+
+
+@pytest.mark.parametrize("cfg,devices,chunk", [("C5", [0, 0, 0], 0), ("C5", [0, 0, 0], 30_000), ("C2", [0, 0], 50_000), ("C4", [0, 0, 0, 0], 0), ("C5", [0], 0)])
+def test_sparse_payload_moves_only_the_live_rays(gpu, cfg, devices, chunk):
+    """ZOIC_FRAME_PAYLOAD_SPARSE: per 256-ray tile a live mask + the compacted rows of the rays with weight != 0 travel; expanded on the
+    root.  Live rows bit-identical to the dense payload, rows of weight-0 rays all zero, and the bytes that moved into the root shrink
+    by the frame's zero-weight share (C5's corner rows: 4.5x), lane_info says by how much.  Back-to-back with the other layouts."""
+    import torch
+    from zoic_amd import FRAME_PAYLOAD_SPARSE
+    c = CONFIGS[cfg]
+    n = 600_000 + 131
+    base = {"C5": 0, "C2": 2_000_000, "C4": 5_000_000}[cfg]       # C5: the frame's first rows, mostly dead pixels
+    ref, _ = single(cfg, n, base, PRECISION_FAST)
+    ref7 = ref[:, :7].contiguous()
+    live = ref7[:, 6] != 0
+    with ZoicFrame(devices) as frame:
+        setup(frame, cfg, PRECISION_FAST)
+        if chunk:
+            frame.set_chunk_rays(chunk)
+        frame.generate_samples(n, c["width"], c["height"], c["spp"], seed=1, ray_index_base=base)
+        dense = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD)
+        torch.cuda.synchronize()
+        dense_bytes = sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices)))
+        sparse = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD_SPARSE)
+        again = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD_SPARSE, out=torch.full_like(sparse, 9.0))   # staging reuse
+        rec = frame.render(n, ray_index_base=base, layout=FRAME_RECORDS)                                               # and another layout behind it
+        torch.cuda.synchronize()
+        sparse_bytes = sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices)))
+        info = [frame.lane_info(i) for i in range(len(devices))]
+    assert torch.equal(dense.view(torch.int32), ref7.view(torch.int32))
+    assert torch.equal(sparse[live].view(torch.int32), ref7[live].view(torch.int32))
+    assert bool((sparse[~live] == 0).all()) and int((~live).sum()) > 0 or cfg == "C4"
+    assert torch.equal(again.view(torch.int32), sparse.view(torch.int32))
+    assert torch.equal(rec.view(torch.int32), ref.view(torch.int32))
+    assert info[0]["bytes_to_root"] == 0 and all(i["peer_access_to_root"] and i["peer_access_from_root"] for i in info)
+    if len(devices) > 1:
+        lo, hi = frame_slab(n, len(devices), 0)
+        peers_live = int(live[hi:].sum())
+        tiles = sum((frame_slab(n, len(devices), i)[1] - frame_slab(n, len(devices), i)[0] + 255) // 256 for i in range(1, len(devices)))
+        assert dense_bytes == 28 * (n - (hi - lo))
+        assert 28 * peers_live <= sparse_bytes <= 28 * peers_live + 48 * (tiles + 64 * len(devices))
+        if cfg == "C5":
+            assert dense_bytes / sparse_bytes > 3.0

@@ -1079,3 +1079,52 @@ def test_batches_beyond_2_to_31_samples_are_split(gpu, cfg, extra):
     assert torch.equal(out["rays"][lo:lo + k].view(torch.int32), ref.view(torch.int32))
     tail = out["rays"][n - 1000:]
     assert bool(torch.isfinite(tail[:, 6]).all().item())   # the last rays were written
+
+
+def test_listed_dead_pixels_do_not_depend_on_the_length_of_the_list(gpu):
+    """A ray's bits must not depend on how a frame is cut.  The decision-safe FAST mode evaluates the rays it cannot decide in a
+    second kernel with three evaluators: long work lists (> 131072 rays: batches + pool), short ones (tries side by side) and the resident
+    kernel's one-ray loop.  A fisheye behind a sensor wider than its image circle has everything at once: 1-2 % of the rays listed, dead
+    pixels (outside the exit-pupil LUT: all 27 tries are one) among them where the LUT ends -- their STRICT try-0 state must be what all
+    three hand out.  One 12.6 M-ray launch (long list) == forty-eight 262144-ray launches (short lists) == tiles through the resident
+    kernel, bit for bit, counters included."""
+    import torch
+    from zoic_amd import PRECISION_FAST, ZoicCamera
+    p = dict(camera_params("C4"), sensorWidth=7.6, sensorHeight=7.6 / 1.5)
+    cam = ZoicCamera(0)
+    cam.update(**p)
+    cam.set_precision(PRECISION_FAST)
+    if cam.info()["fastRunsStrict"]:
+        pytest.skip("the self-check sent this camera to STRICT: nothing is listed")
+    W, H, spp = 1920, 1080, 6
+    n = W * H * spp
+    s = cam.generate_samples(n, W, H, spp, seed=3)
+    cam.reset_counters()
+    whole = cam.create_rays(s)["rays"].clone()
+    torch.cuda.synchronize()
+    c_whole = cam.counters()
+    lut_miss = (whole[:, 7].view(torch.int32) & 64) != 0
+    assert 0.02 < float(lut_miss.float().mean()) < 0.9, "the sensor must reach beyond the LUT"
+    cam.reset_counters()
+    piece = 1 << 18
+    parts = torch.empty_like(whole)
+    for a in range(0, n, piece):
+        b = min(n, a + piece)
+        parts[a:b] = cam.create_rays(s[a:b], ray_index_base=a)["rays"]
+    torch.cuda.synchronize()
+    c_parts = cam.counters()
+    diff = (whole.view(torch.int32) != parts.view(torch.int32)).any(1)
+    assert int(diff.sum()) == 0, (int(diff.sum()), torch.nonzero(diff)[:5].flatten().tolist())
+    assert c_whole == c_parts
+    # ... and the resident kernel's evaluator on a stretch that crosses the LUT's end
+    rows = torch.nonzero(lut_miss)[:, 0]
+    a = max(0, int(rows[len(rows) // 2]) - 30000)
+    m = 60000
+    host = s[a:a + m].cpu().numpy()
+    inp = np.zeros((m, 7), np.float32)
+    inp[:, 0], inp[:, 1], inp[:, 4], inp[:, 5] = host[:, 0], host[:, 1], host[:, 2], host[:, 3]
+    out = cam.create_rays_tile(inp, ray_index_base=a, tid=0)
+    ref = whole[a:a + m].cpu().numpy()
+    assert np.array_equal(out[:, 0:6].view(np.uint32), ref[:, 0:6].view(np.uint32))
+    assert np.array_equal(out[:, 18], ref[:, 6])
+    cam.close()

@@ -236,3 +236,48 @@ def test_bench_launches_its_own_ranks_over_gloo():
     if _capi.load().zoic_device_count() < 2:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode != 0 and "--gpus 2 but only" in (r.stdout + r.stderr)
+
+
+def _sparse_worker(rank, world, port, n, chunk_bytes, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from zoic_amd.sharding import ShardedFrame
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frame = ShardedFrame(n, dist, torch.device("cpu"), _oracle_generate(n), dst=0, chunk_bytes=chunk_bytes, sparse=True)
+    for step in range(2):
+        full = frame.run(gather=True)
+    if rank == 0:
+        np.save(os.path.join(outdir, "sparse.npy"), full.numpy())
+        np.save(os.path.join(outdir, "bytes.npy"), np.array([frame.root_bytes]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_gather_ships_only_the_live_rays(tmp_path, oracle_lib):
+    """ShardedFrame(sparse=True) at world 3 over gloo: live rows bit-identical to the single-process frame, rows of weight-0 rays zero,
+    and the root receives 28 bytes per LIVE peer ray + a bit per ray + a count per chunk (the dense gather: 28 bytes per ray)."""
+    import torch.multiprocessing as mp
+    from zoic_amd.sharding import all_slabs
+    from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
+    world, n, chunk_bytes = 3, 10_001, 28 * 1024
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_sparse_worker, args=(world, port, n, chunk_bytes, str(tmp_path)), nprocs=world, join=True)
+    c = CONFIGS["C2"]
+    oc = oracle_lib.OracleCamera().update(**camera_params("C2"))
+    ref = oc.create_rays(synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1), rng_states=ray_rng_states(n, 1, 0))
+    got = np.load(tmp_path / "sparse.npy")
+    planes = np.ascontiguousarray(ref["planes"].T)
+    live = planes[:, 6] != 0
+    assert live.sum() > 100 and (~live).sum() > 100
+    assert np.array_equal(got[live].view(np.uint32), planes[live].view(np.uint32))
+    assert (got[~live] == 0).all()
+    lo, hi = all_slabs(n, world)[0]
+    peers_live = int(live[hi:].sum())
+    moved = int(np.load(tmp_path / "bytes.npy")[0])
+    assert 28 * peers_live <= moved <= 28 * peers_live + (n - hi) // 8 + 200
+    assert moved < 0.95 * 28 * (n - hi)

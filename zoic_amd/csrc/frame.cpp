@@ -61,6 +61,15 @@ struct Lane {
     bool doneRecorded[3] = {false, false, false};
     hipEvent_t samplesReady = nullptr;                        // zoic_frame_generate_samples' kernel
     std::vector<hipEvent_t> computed;                         // per chunk: trace (+ pack) done
+    // ZOIC_FRAME_PAYLOAD_SPARSE: a chunk travels as [tile headers][rows of the rays with weight != 0]; its size is known on the device
+    hipStream_t rootExpand = nullptr;                         // on the ROOT device: the expansion of this lane's chunks into the caller's rows
+    hipEvent_t expandDone = nullptr;                          // ... its tail for the call in flight (root device)
+    bool expandRecorded = false;
+    std::vector<hipEvent_t> copied, expanded;                 // per chunk: peer copy landed (this device) / expanded into the output (root device)
+    DeviceBuffer<uint32_t> sparse[2];                         // this device: headers + compacted rows of the chunks in flight
+    unsigned int *dCount = nullptr;                           // this device: live rays per chunk (kMaxChunksPerSlab dwords)
+    unsigned int *hCount = nullptr;                           // page-locked: the same, read by the host before it sizes the copy
+    DeviceBuffer<uint32_t> rootStage[2];                      // ROOT device: where the chunks land
     // what the last render_device call did on this lane (zoic_frame_get_lane_info)
     int peerToRoot = 0, rootToPeer = 0;                       // hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess both succeeded
     uint64_t lastRays = 0, lastBytesToRoot = 0; uint32_t lastChunks = 0;
@@ -111,6 +120,8 @@ zoic_status order_behind_previous(Lane &L)
     for (hipStream_t s : {L.compute[0], L.compute[1], L.copy})
         for (int t = 0; t < 3; ++t)
             if (L.doneRecorded[t]) FRAME_HIP(hipStreamWaitEvent(s, L.streamDone[t], 0));
+    if (L.expandRecorded)   // a sparse gather's expansion still reads the root's staging of this lane
+        for (hipStream_t s : {L.compute[0], L.compute[1], L.copy}) FRAME_HIP(hipStreamWaitEvent(s, L.expandDone, 0));
     return ZOIC_OK;
 }
 
@@ -203,7 +214,17 @@ void zoic_frame_destroy(zoic_frame *frame)
             for (hipEvent_t &e : L.streamDone) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             if (L.samplesReady) (void)hipEventDestroy(L.samplesReady);
             for (hipEvent_t e : L.computed) (void)hipEventDestroy(e);
-            L.samples.release(); L.records.release(); L.payload.release();
+            L.samples.release(); L.records.release(); L.payload.release(); L.sparse[0].release(); L.sparse[1].release();
+            for (hipEvent_t e : L.copied) (void)hipEventDestroy(e);
+            if (L.dCount) (void)hipFree(L.dCount);
+            if (L.hCount) (void)hipHostFree(L.hCount);
+            {
+                DeviceGuard rootGuard(frame->lanes[0].device);
+                if (L.rootExpand) (void)hipStreamDestroy(L.rootExpand);
+                if (L.expandDone) (void)hipEventDestroy(L.expandDone);
+                for (hipEvent_t e : L.expanded) (void)hipEventDestroy(e);
+                L.rootStage[0].release(); L.rootStage[1].release();
+            }
             if (&L == &frame->lanes[0] && frame->rootStart) (void)hipEventDestroy(frame->rootStart);
         }
         zoic_camera_destroy(L.cam);
@@ -308,7 +329,7 @@ zoic_status settle_after_failure(zoic_frame *frame, zoic_status st)
 {
     const std::string why = zoic_last_error_string();
     (void)zoic_frame_synchronize(frame);
-    for (Lane &L : frame->lanes) for (bool &r : L.doneRecorded) r = false;   // everything has drained: nothing left to order behind
+    for (Lane &L : frame->lanes) { for (bool &r : L.doneRecorded) r = false; L.expandRecorded = false; }   // everything has drained: nothing left to order behind
     return fail_status(st, why);
 }
 
@@ -430,6 +451,151 @@ zoic_status render_local_impl(zoic_frame *frame, uint64_t n, const float *const 
     return ZOIC_OK;
 }
 
+// ZOIC_FRAME_PAYLOAD_SPARSE.  SURVEY 8(e)'s gather ships 28 bytes for every ray; a ray with weight 0 -- four fifths of a wide-open
+// PETZVAL frame (zoic.cpp:1951-1953), a fifth of a TESSAR's -- carries nothing a consumer reads.  A peer's chunk travels as a
+// 256-bit live mask per 256-ray tile + the compacted 28-byte rows of the rays with weight != 0 (pack_sparse_kernel) and is
+// expanded on the root (rows of weight-0 rays: seven zeros; their origin / direction -- the reference's partial state -- and their
+// try counts stay on the device that traced them).  The size of a chunk is only known on the device: the host reads the chunk's
+// live count (4 bytes, page-locked) before it queues the copy, i.e. it waits for the chunk's trace -- with the NEXT chunk of every
+// lane already queued, so no device idles.  The loop runs chunk-major over the lanes for that reason; the call returns when the
+// last chunk's size is known (the copies and expansions may still be in flight behind root_stream, as with the other layouts).
+zoic_status render_sparse_impl(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, void *d_out, void *root_stream)
+{
+    const int nd = static_cast<int>(frame->lanes.size());
+    Lane &R = frame->lanes[0];
+    hipStream_t rootStream = static_cast<hipStream_t>(root_stream);
+    char *const out = static_cast<char *>(d_out);
+    {
+        DeviceGuard guard(R.device);
+        FRAME_HIP(guard.error());
+        FRAME_HIP(hipEventRecord(frame->rootStart, rootStream));
+    }
+    struct Plan { uint64_t lo = 0, hi = 0, chunk = 0; size_t chunks = 0; const float *samples = nullptr; };
+    std::vector<Plan> plan(static_cast<size_t>(nd));
+    size_t rounds = 0;
+    for (int i = 0; i < nd; ++i) {
+        Lane &L = frame->lanes[static_cast<size_t>(i)];
+        Plan &P = plan[static_cast<size_t>(i)];
+        slab_of(n, nd, i, P.lo, P.hi);
+        L.lastRays = P.hi - P.lo; L.lastBytesToRoot = 0; L.lastChunks = 0;
+        if (P.hi <= P.lo) continue;
+        if (zoic_status s = lane_samples(frame, L, static_cast<size_t>(i), d_samples, n, ray_index_base, P.samples)) return s;
+        const uint64_t slab = P.hi - P.lo;
+        P.chunk = i == 0 ? slab : chunk_rays_for(frame, slab, 28);
+        P.chunks = static_cast<size_t>((slab + P.chunk - 1) / P.chunk);
+        L.lastChunks = static_cast<uint32_t>(P.chunks);
+        rounds = std::max(rounds, P.chunks);
+        DeviceGuard guard(L.device);
+        FRAME_HIP(guard.error());
+        if (zoic_status s = order_behind_previous(L)) return s;
+        if (zoic_status s = ensure_chunk_events(L, P.chunks)) return s;
+        if (L.records.cap < slab) {
+            for (hipStream_t s : {L.compute[0], L.compute[1], L.copy}) FRAME_HIP(hipStreamSynchronize(s));
+            FRAME_HIP(L.records.reserve(slab));
+        }
+        for (hipStream_t s : {L.compute[0], L.compute[1]}) {
+            FRAME_HIP(hipStreamWaitEvent(s, frame->rootStart, 0));
+            if (!d_samples) FRAME_HIP(hipStreamWaitEvent(s, L.samplesReady, 0));
+        }
+        if (i == 0) continue;
+        FRAME_HIP(hipStreamWaitEvent(L.copy, frame->rootStart, 0));
+        const size_t words = (sparse_header_bytes(P.chunk) + static_cast<size_t>(P.chunk) * 28u) / 4u;
+        while (L.copied.size() < P.chunks) { hipEvent_t e = nullptr; FRAME_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); L.copied.push_back(e); }
+        if (!L.dCount) FRAME_HIP(hipMalloc(reinterpret_cast<void **>(&L.dCount), kMaxChunksPerSlab * sizeof(unsigned int)));
+        if (!L.hCount) FRAME_HIP(hipHostMalloc(reinterpret_cast<void **>(&L.hCount), kMaxChunksPerSlab * sizeof(unsigned int), hipHostMallocDefault));
+        for (int b = 0; b < 2; ++b)
+            if (L.sparse[b].cap < words) {
+                for (hipStream_t s : {L.compute[0], L.compute[1], L.copy}) FRAME_HIP(hipStreamSynchronize(s));
+                FRAME_HIP(L.sparse[b].reserve(words));
+            }
+        {   // the root's side of this lane
+            DeviceGuard rootGuard(R.device);
+            FRAME_HIP(rootGuard.error());
+            if (!L.rootExpand) FRAME_HIP(hipStreamCreateWithFlags(&L.rootExpand, hipStreamNonBlocking));
+            if (!L.expandDone) FRAME_HIP(hipEventCreateWithFlags(&L.expandDone, hipEventDisableTiming));
+            while (L.expanded.size() < P.chunks) { hipEvent_t e = nullptr; FRAME_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); L.expanded.push_back(e); }
+            for (int b = 0; b < 2; ++b)
+                if (L.rootStage[b].cap < words) { FRAME_HIP(hipStreamSynchronize(L.rootExpand)); FRAME_HIP(L.rootStage[b].reserve(words)); }
+            FRAME_HIP(hipStreamWaitEvent(L.rootExpand, frame->rootStart, 0));   // d_out's previous readers first
+        }
+    }
+    // chunk k of a peer: its live count is on the host -> the copy, sized; then the expansion on the root
+    const auto finish_chunk = [&](int i, size_t k) -> zoic_status {
+        Lane &L = frame->lanes[static_cast<size_t>(i)];
+        const Plan &P = plan[static_cast<size_t>(i)];
+        const uint64_t a = P.lo + k * P.chunk, b = std::min(P.hi, a + P.chunk), m = b - a;
+        DeviceGuard guard(L.device);
+        FRAME_HIP(guard.error());
+        FRAME_HIP(hipEventSynchronize(L.computed[k]));
+        const size_t bytes = sparse_header_bytes(m) + static_cast<size_t>(L.hCount[k]) * 28u;
+        FRAME_HIP(hipStreamWaitEvent(L.copy, L.computed[k], 0));
+        if (k >= 2) FRAME_HIP(hipStreamWaitEvent(L.copy, L.expanded[k - 2], 0));   // the root's staging buffer is free again
+        if (L.device == R.device) FRAME_HIP(hipMemcpyAsync(L.rootStage[k & 1].ptr, L.sparse[k & 1].ptr, bytes, hipMemcpyDeviceToDevice, L.copy));
+        else FRAME_HIP(hipMemcpyPeerAsync(L.rootStage[k & 1].ptr, R.device, L.sparse[k & 1].ptr, L.device, bytes, L.copy));
+        FRAME_HIP(hipEventRecord(L.copied[k], L.copy));
+        L.lastBytesToRoot += bytes;
+        DeviceGuard rootGuard(R.device);
+        FRAME_HIP(rootGuard.error());
+        FRAME_HIP(hipStreamWaitEvent(L.rootExpand, L.copied[k], 0));
+        if (int rc = launch_expand_sparse(L.rootStage[k & 1].ptr, reinterpret_cast<float *>(out + a * 28u), m, L.rootExpand))
+            return fail_status(ZOIC_ERR_HIP, std::string("expand kernel: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        FRAME_HIP(hipEventRecord(L.expanded[k], L.rootExpand));
+        return ZOIC_OK;
+    };
+    for (size_t k = 0; k < rounds + 1; ++k) {
+        for (int i = 0; i < nd && k < rounds; ++i) {
+            Lane &L = frame->lanes[static_cast<size_t>(i)];
+            const Plan &P = plan[static_cast<size_t>(i)];
+            if (k >= P.chunks) continue;
+            const uint64_t a = P.lo + k * P.chunk, b = std::min(P.hi, a + P.chunk), m = b - a;
+            DeviceGuard guard(L.device);
+            FRAME_HIP(guard.error());
+            hipStream_t cs = L.compute[k & 1];
+            zoic_ray *dst = L.records.ptr + (a - P.lo);
+            if (zoic_status s = zoic_create_rays_device(L.cam, m, P.samples + (a - P.lo) * 4, nullptr, ray_index_base + a, dst, cs)) return s;
+            if (i == 0) {   // the root's own slab: the same rows, straight into the output
+                if (int rc = launch_pack_payload_live(reinterpret_cast<const RayRecord *>(dst), reinterpret_cast<float *>(out + a * 28u), m, cs))
+                    return fail_status(ZOIC_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+                continue;
+            }
+            if (k >= 2) FRAME_HIP(hipStreamWaitEvent(cs, L.copied[k - 2], 0));   // this device's sparse buffer has left
+            FRAME_HIP(hipMemsetAsync(L.dCount + k, 0, sizeof(unsigned int), cs));
+            if (int rc = launch_pack_sparse(reinterpret_cast<const RayRecord *>(dst), L.sparse[k & 1].ptr, L.dCount + k, m, cs))
+                return fail_status(ZOIC_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+            FRAME_HIP(hipMemcpyAsync(L.hCount + k, L.dCount + k, sizeof(unsigned int), hipMemcpyDeviceToHost, cs));
+            FRAME_HIP(hipEventRecord(L.computed[k], cs));
+        }
+        if (k == 0) continue;
+        for (int i = 1; i < nd; ++i)
+            if (k - 1 < plan[static_cast<size_t>(i)].chunks)
+                if (zoic_status s = finish_chunk(i, k - 1)) return s;
+    }
+    // the caller's root stream continues behind everything
+    for (int i = 0; i < nd; ++i) {
+        Lane &L = frame->lanes[static_cast<size_t>(i)];
+        if (plan[static_cast<size_t>(i)].chunks == 0) continue;
+        DeviceGuard guard(L.device);
+        FRAME_HIP(guard.error());
+        hipStream_t tails[3] = {L.compute[0], L.compute[1], L.copy};
+        for (int t = 0; t < 3; ++t) {
+            if (i == 0 && t > 0) continue;   // the root lane is one launch on compute[0]
+            FRAME_HIP(hipEventRecord(L.streamDone[t], tails[t]));
+            L.doneRecorded[t] = true;
+            DeviceGuard rootGuard(R.device);
+            FRAME_HIP(rootGuard.error());
+            FRAME_HIP(hipStreamWaitEvent(rootStream, L.streamDone[t], 0));
+        }
+        if (i > 0) {
+            DeviceGuard rootGuard(R.device);
+            FRAME_HIP(rootGuard.error());
+            FRAME_HIP(hipEventRecord(L.expandDone, L.rootExpand));
+            L.expandRecorded = true;
+            FRAME_HIP(hipStreamWaitEvent(rootStream, L.expandDone, 0));
+        }
+    }
+    return ZOIC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -438,9 +604,13 @@ zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float 
                                      zoic_frame_layout layout, void *root_stream)
 {
     if (!frame) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "frame is NULL");
-    if (layout != ZOIC_FRAME_RECORDS && layout != ZOIC_FRAME_PAYLOAD) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "bad layout");
+    if (layout != ZOIC_FRAME_RECORDS && layout != ZOIC_FRAME_PAYLOAD && layout != ZOIC_FRAME_PAYLOAD_SPARSE) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "bad layout");
     if (n == 0) return ZOIC_OK;
     if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15u)) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "d_out must be non-NULL and 16-byte aligned");
+    if (layout == ZOIC_FRAME_PAYLOAD_SPARSE) {
+        if (zoic_status s = render_sparse_impl(frame, n, d_samples, ray_index_base, d_out, root_stream)) return settle_after_failure(frame, s);
+        return ZOIC_OK;
+    }
     if (zoic_status s = render_device_impl(frame, n, d_samples, ray_index_base, d_out, layout, root_stream)) return settle_after_failure(frame, s);
     return ZOIC_OK;
 }
@@ -498,6 +668,11 @@ zoic_status zoic_frame_synchronize(zoic_frame *frame)
         FRAME_HIP(guard.error());
         for (hipStream_t s : {L.compute[0], L.compute[1], L.copy})
             if (s) FRAME_HIP(hipStreamSynchronize(s));
+        if (L.rootExpand) {
+            DeviceGuard rootGuard(frame->lanes[0].device);
+            FRAME_HIP(rootGuard.error());
+            FRAME_HIP(hipStreamSynchronize(L.rootExpand));
+        }
     }
     return ZOIC_OK;
 }

@@ -175,6 +175,74 @@ __global__ __launch_bounds__(kBlock) void pack_payload_kernel(const RayRecord *_
     }
 }
 
+// ------------------------------------------------------------------------------------- sparse payload (kernels.hpp)
+// One workgroup per 256-ray tile: ballot per wave -> the tile's 256-bit mask, one atomicAdd for its row range, every live lane
+// writes its 28-byte row at (range start + its rank).  SURVEY 8(e)'s gather ships 28 B for every ray; on a wide-open PETZVAL four
+// fifths of them have weight 0 (zoic.cpp:1951-1953) and nothing downstream reads their origin / direction.
+__global__ __launch_bounds__(kBlock) void pack_sparse_kernel(const RayRecord *__restrict__ rays, uint32_t *__restrict__ sparse, unsigned int *count, uint64_t m)
+{
+    __shared__ uint32_t waveCount[kBlock / 64];
+    __shared__ uint32_t tileBase;
+    const uint64_t tiles = (m + kSparseTileRays - 1) / kSparseTileRays;
+    float *rows = reinterpret_cast<float *>(sparse + tiles * kSparseTileWords);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t i = tile * kSparseTileRays + threadIdx.x;
+        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (i < m) {
+            const float4 a = reinterpret_cast<const float4 *>(rays + i)[0], b = reinterpret_cast<const float4 *>(rays + i)[1];
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z;
+        }
+        const bool live = i < m && r[6] != 0.0f;
+        const unsigned long long mask = __ballot(live);
+        uint32_t *hdr = sparse + tile * kSparseTileWords;
+        if (lane == 0) { hdr[2 * wave] = static_cast<uint32_t>(mask); hdr[2 * wave + 1] = static_cast<uint32_t>(mask >> 32); waveCount[wave] = static_cast<uint32_t>(__popcll(mask)); }
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) { if (w < wave) before += waveCount[w]; total += waveCount[w]; }
+        if (threadIdx.x == 0) { tileBase = atomicAdd(count, total); hdr[8] = tileBase; hdr[9] = total; hdr[10] = 0u; hdr[11] = 0u; }
+        __syncthreads();
+        if (live) {
+            const uint32_t rank = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+            float *dst = rows + static_cast<size_t>(tileBase + rank) * 7u;
+#pragma unroll
+            for (int f = 0; f < 7; ++f) dst[f] = r[f];
+        }
+        __syncthreads();   // waveCount / tileBase are reused by the next tile
+    }
+}
+
+// one lane per output float (coalesced stores); a ray's row index = its tile's offset + the live rays before it in the tile
+__global__ __launch_bounds__(kBlock) void expand_sparse_kernel(const uint32_t *__restrict__ sparse, float *__restrict__ out7, uint64_t m)
+{
+    const uint64_t tiles = (m + kSparseTileRays - 1) / kSparseTileRays;
+    const float *rows = reinterpret_cast<const float *>(sparse + tiles * kSparseTileWords);
+    const uint64_t total = m * 7u, stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t ray = t / 7u;
+        const uint32_t f = static_cast<uint32_t>(t - ray * 7u);
+        const uint32_t *hdr = sparse + (ray / kSparseTileRays) * kSparseTileWords;
+        const uint32_t in = static_cast<uint32_t>(ray % kSparseTileRays), word = in >> 5, bit = in & 31u;
+        float v = 0.0f;
+        if ((hdr[word] >> bit) & 1u) {
+            uint32_t rank = __builtin_popcount(hdr[word] & ((1u << bit) - 1u));
+            for (uint32_t w = 0; w < word; ++w) rank += __builtin_popcount(hdr[w]);
+            v = rows[static_cast<size_t>(hdr[8] + rank) * 7u + f];
+        }
+        out7[t] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void pack_payload_live_kernel(const RayRecord *__restrict__ rays, float *__restrict__ out7, uint64_t n)
+{
+    const uint64_t total = n * 7u, stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t ray = t / 7u;
+        const float *r = reinterpret_cast<const float *>(rays + ray);
+        out7[t] = r[6] != 0.0f ? r[static_cast<uint32_t>(t - ray * 7u)] : 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------- launchers
 static inline unsigned grid_for(uint64_t n)
 {
@@ -230,6 +298,28 @@ int launch_pack_payload(const RayRecord *d_rays, float *d_out7, uint64_t n, void
 {
     if (n == 0) return 0;
     hipLaunchKernelGGL(pack_payload_kernel, dim3(grid_for(n * 7u)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_rays, d_out7, n);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_pack_sparse(const RayRecord *d_rays, uint32_t *d_sparse, unsigned int *d_count, uint64_t m, void *stream)
+{
+    if (m == 0) return 0;
+    const uint64_t tiles = (m + kSparseTileRays - 1) / kSparseTileRays;
+    hipLaunchKernelGGL(pack_sparse_kernel, dim3(static_cast<unsigned>(tiles < 8192 ? tiles : 8192)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_rays, d_sparse, d_count, m);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_expand_sparse(const uint32_t *d_sparse, float *d_out7, uint64_t m, void *stream)
+{
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(expand_sparse_kernel, dim3(grid_for(m * 7u)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_sparse, d_out7, m);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_pack_payload_live(const RayRecord *d_rays, float *d_out7, uint64_t n, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_payload_live_kernel, dim3(grid_for(n * 7u)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), d_rays, d_out7, n);
     return static_cast<int>(hipGetLastError());
 }
 

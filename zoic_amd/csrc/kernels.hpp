@@ -87,4 +87,16 @@ int launch_expand_outputs(const RayRecord *d_rays, float *d_out21, uint64_t n, v
 // records -> 28-byte payload rows (ox oy oz dx dy dz weight): what a multi-device frame moves to its root (frame.cpp)
 int launch_pack_payload(const RayRecord *d_rays, float *d_out7, uint64_t n, void *stream);
 
+// ---- sparse payload (frame.cpp, ZOIC_FRAME_PAYLOAD_SPARSE): a chunk of m records as [per 256-ray tile: 256-bit live mask, offset, count]
+// [the 28-byte rows of the rays with weight != 0, compacted].  d_sparse: kSparseTileWords dwords per tile, then the rows; d_count: one
+// dword, zero on entry, the number of live rays on exit.  Tiles take their row ranges with one atomicAdd each: the ORDER of the tiles'
+// ranges is whatever the hardware made it, their content is not (a tile's header says where its rows are).
+constexpr unsigned kSparseTileRays = 256, kSparseTileWords = 12;   // mask[8], row offset, live count, 2 x pad: 48 bytes per tile
+inline size_t sparse_header_bytes(uint64_t m) { return static_cast<size_t>((m + kSparseTileRays - 1) / kSparseTileRays) * kSparseTileWords * 4u; }
+int launch_pack_sparse(const RayRecord *d_rays, uint32_t *d_sparse, unsigned int *d_count, uint64_t m, void *stream);
+// the inverse on the root: m rows of 7 floats, the rows of weight-0 rays all zero
+int launch_expand_sparse(const uint32_t *d_sparse, float *d_out7, uint64_t m, void *stream);
+// the root's own slab in the same convention: payload rows with the rows of weight-0 rays zeroed
+int launch_pack_payload_live(const RayRecord *d_rays, float *d_out7, uint64_t n, void *stream);
+
 }  // namespace zoic

@@ -130,6 +130,16 @@ __device__ __forceinline__ ListedRay listed_one_ray(const KolbTable &T, const Bo
     }
     r.o = o0;
     bool ok = listed_strict_try(T, r.o, r.d, r.tir);
+    // a dead pixel's 26 retries repeat its first try bit for bit (kolb_pool_body.hpp): try 0's STRICT state stands, as in pass A of the
+    // long lists below -- a listed ray's bits do not depend on which of the three evaluators it met
+    if (!ok && rs.dead) {
+        const bool plainSample = (s.z >= 0.0f) & (s.z < 1.0f) & (s.w >= 0.0f) & (s.w < 1.0f) & !((s.z == 0.5f) & (s.w == 0.5f));
+        const V2 l0 = lens_sample<true>(T, B, bokehLds, s.z, s.w);
+        if (plainSample || ((fabsf(l0.x) <= 3.0e38f) && (fabsf(l0.y) <= 3.0e38f))) {
+            r.tir += r.tir * (static_cast<uint32_t>(kMaxTries) + 1u);
+            r.tries = static_cast<uint32_t>(kMaxTries) + 1u;
+        }
+    }
     while (!ok && r.tries <= static_cast<uint32_t>(kMaxTries)) {      // zoic.cpp:1927
         const float u = rng_unit(xor128(rng));                        // zoic.cpp:1930
         const float v = rng_unit(xor128(rng));
@@ -179,6 +189,12 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
         else rng = rng_for_ray(T.seed, rayBase + idx);
         for (uint32_t a = 1; a < j; ++a) { (void)xor128(rng); (void)xor128(rng); }   // lane j >= 1 starts at draw 2 (j - 1)
         bool done = !have;
+        // a dead pixel (outside the image circle) whose try 0 fails: its 26 retries are that try again (kolb_pool_body.hpp)
+        bool deadPixel = rs.dead;
+        if (deadPixel) {
+            const bool plainSample = (s.z >= 0.0f) & (s.z < 1.0f) & (s.w >= 0.0f) & (s.w < 1.0f) & !((s.z == 0.5f) & (s.w == 0.5f));
+            if (!plainSample) { const V2 l0 = lens_sample<true>(T, B, bokehLds, s.z, s.w); deadPixel = (fabsf(l0.x) <= 3.0e38f) && (fabsf(l0.y) <= 3.0e38f); }
+        }
         for (uint32_t round = 0; round * kShortGroup <= static_cast<uint32_t>(kMaxTries) + 1u; ++round) {
             const uint32_t k = kShortGroup * round + j;                      // this lane's try: 0 = the sample's own lens point, k = tries
             const bool valid = !done && k <= static_cast<uint32_t>(kMaxTries) + 1u;
@@ -187,7 +203,7 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
             bool ok = false, unsure = false;
             float u = 0.0f, v = 0.0f;
             // every lane's direction first; then ONE FAST-guarded trace for the tries k >= 1 of the whole wave -- the predicated trace of
-            // the long-list path, so that a ray's bits do not depend on the path (the rolled trace contracts its FMAs differently) --
+            // the long-list path, so that a ray's bits do not depend on the path (one arithmetic, written with explicit FMAs: fast_optics.hpp) --
             // and the reference's arithmetic for try 0 and for the tries that were too close to call
             if (valid) {
                 if (k == 0u) {
@@ -240,17 +256,31 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
             const unsigned long long okAll = __ballot(valid && ok);
             const uint32_t okGroup = static_cast<uint32_t>(okAll >> (kShortGroup * g)) & ((1u << kShortGroup) - 1u);
             const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : kShortGroup;   // lowest try that got through
-            if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
-            const bool last = k == static_cast<uint32_t>(kMaxTries) + 1u;      // try 26 failed as well: weight 0, ITS partial state
-            if (valid && (j == winner || (winner == kShortGroup && last))) {
-                const bool okRay = j == winner && !last;
-                float w = okRay ? 1.0f : 0.0f;
-                if (T.exposureOn) w *= T.exposureMul;                          // zoic.cpp:1981-1987
-                store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
-                                 (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6));
-                if (okRay) ++succ; else ++vign;
+            // a dead pixel whose try 0 failed: 26 identical failures follow -- ITS (STRICT) state with weight 0 and 27 x its TIR bump, as pass
+            // A of the long lists hands it out (the other lanes' speculative tries of this ray count for nothing)
+            const bool deadEnd = round == 0u && deadPixel && (okGroup & 1u) == 0u && !done;
+            const uint32_t kOutTries = static_cast<uint32_t>(kMaxTries) + 1u;
+            if (deadEnd) {
+                if (valid && j == 0u) {
+                    tir += (kOutTries + 1u) * tirTry;
+                    float w = 0.0f;
+                    if (T.exposureOn) w *= T.exposureMul;                      // zoic.cpp:1981-1987
+                    store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, 1u | (kOutTries << 1) | ((rs.flags & 1u) << 6));
+                    ++vign;
+                }
+            } else {
+                if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
+                const bool last = k == kOutTries;                                  // try 26 failed as well: weight 0, ITS partial state
+                if (valid && (j == winner || (winner == kShortGroup && last))) {
+                    const bool okRay = j == winner && !last;
+                    float w = okRay ? 1.0f : 0.0f;
+                    if (T.exposureOn) w *= T.exposureMul;                          // zoic.cpp:1981-1987
+                    store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
+                                     (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6));
+                    if (okRay) ++succ; else ++vign;
+                }
             }
-            done = done || winner != kShortGroup || kShortGroup * (round + 1u) > static_cast<uint32_t>(kMaxTries) + 1u;
+            done = done || deadEnd || winner != kShortGroup || kShortGroup * (round + 1u) > kOutTries;
             if (__ballot(!done) == 0ull) break;
         }
     }

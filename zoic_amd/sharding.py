@@ -70,12 +70,18 @@ class ShardedFrame:
     The root's `full` tensor is (n_total, 7) payload.  Reusable across steps (buffers are allocated once)."""
 
     def __init__(self, n_total, dist, device, generate, dst=0, chunk_bytes=None, tile=TILE, payload_floats=PAYLOAD_FLOATS,
-                 min_chunk_bytes=64 << 20, chunks_per_slab=4):
+                 min_chunk_bytes=64 << 20, chunks_per_slab=4, sparse=False):
         import torch
         self.torch, self.dist, self.device, self.generate, self.dst = torch, dist, device, generate, dst
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self.n_total, self.k = n_total, payload_floats
+        # sparse=True (= ZOIC_FRAME_PAYLOAD_SPARSE of the C-ABI): only the rays with weight != 0 travel -- per chunk a live bit per
+        # ray and the compacted rows; rows of weight-0 rays arrive as zeros (their origin / direction, the reference's partial state
+        # of the last try, and their try counts stay on the rank that traced them).  A chunk's size is then only known to its
+        # sender: every round starts with the peers' live counts (one small message each), the root sizes its receives from them.
+        self.sparse = bool(sparse)
+        self.root_bytes = 0          # bytes received by the root in the last run(gather=True)
         self.slabs = all_slabs(n_total, self.world, tile)
         if chunk_bytes is None:
             # A sub-launch has ~0.1 ms of fixed cost (start-up + the tail of its unluckiest rays) against ~0.03 ms of
@@ -110,10 +116,78 @@ class ShardedFrame:
         self.slots = 3          # generate() may rotate this many record buffers: chunk k may only overwrite chunk k - 3's
         self.slot_free = [None] * self.slots
 
+    def _run_sparse(self):
+        """The gather with only the live rays on the wire.  Per round: every rank queues its chunk's trace; peers pack (live bits +
+        compacted rows), send the count, then the packed chunk; the root receives the counts, sizes and posts the receives, expands."""
+        import contextlib
+        torch, dist = self.torch, self.dist
+        mine = self.chunks[self.rank]
+        caller = torch.cuda.current_stream(self.device) if self.cuda else None
+        if self.cuda:
+            for cs in self.compute_streams:
+                cs.wait_stream(caller)
+        self.root_bytes = 0
+        if self.rank == self.dst:
+            self.full.zero_()      # rows of weight-0 rays
+        for k in range(self.rounds):
+            cs = self.compute_streams[k & 1] if self.cuda else None
+            with (torch.cuda.stream(cs) if self.cuda else contextlib.nullcontext()):
+                rec = None
+                if k < len(mine):
+                    a, b = mine[k]
+                    rec = self.generate(a, b)
+                if self.rank == self.dst:
+                    if rec is not None:
+                        pay = rec[:, :self.k]
+                        self.full[a:b].copy_(pay * (pay[:, 6:7] != 0))     # the root's own slab in the same convention
+                    peers = [r for r in range(self.world) if r != self.dst and k < len(self.chunks[r])]
+                    counts = {r: torch.zeros(1, dtype=torch.int64, device=self.device) for r in peers}
+                    for q in (dist.batch_isend_irecv([dist.P2POp(dist.irecv, counts[r], r) for r in peers]) if peers else []):
+                        q.wait()
+                    bufs, ops = {}, []
+                    for r in peers:
+                        ra, rb = self.chunks[r][k]
+                        live = int(counts[r].item())
+                        bufs[r] = (torch.empty(((rb - ra + 7) // 8,), dtype=torch.uint8, device=self.device),
+                                   torch.empty((live, self.k), dtype=torch.float32, device=self.device))
+                        ops.append(dist.P2POp(dist.irecv, bufs[r][0], r))
+                        if live:
+                            ops.append(dist.P2POp(dist.irecv, bufs[r][1], r))
+                        self.root_bytes += bufs[r][0].numel() + 4 * self.k * live + 8
+                    for q in (dist.batch_isend_irecv(ops) if ops else []):
+                        q.wait()
+                    for r in peers:
+                        ra, rb = self.chunks[r][k]
+                        bits, rows = bufs[r]
+                        live_mask = ((bits[:, None] >> torch.arange(8, device=self.device, dtype=torch.uint8)[None, :]) & 1).reshape(-1)[: rb - ra].bool()
+                        self.full[ra:rb][live_mask] = rows
+                elif rec is not None:
+                    pay = rec[:, :self.k]
+                    live_mask = pay[:, 6] != 0
+                    rows = pay[live_mask].contiguous()
+                    m = b - a
+                    padded = torch.zeros(((m + 7) // 8) * 8, dtype=torch.uint8, device=self.device)
+                    padded[:m] = live_mask.to(torch.uint8)
+                    bits = (padded.reshape(-1, 8) << torch.arange(8, device=self.device, dtype=torch.uint8)[None, :]).sum(1).to(torch.uint8)
+                    count = torch.tensor([rows.shape[0]], dtype=torch.int64, device=self.device)
+                    for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, count, self.dst)]):
+                        q.wait()
+                    ops = [dist.P2POp(dist.isend, bits, self.dst)]
+                    if rows.shape[0]:
+                        ops.append(dist.P2POp(dist.isend, rows, self.dst))
+                    for q in dist.batch_isend_irecv(ops):
+                        q.wait()
+        if self.cuda:
+            for cs in self.compute_streams:
+                caller.wait_stream(cs)
+        return self.full
+
     def run(self, gather=True):
         """Render this rank's slab chunk by chunk; with gather=True the payload of chunk k travels while chunk k+1 is
         traced.  Returns the root's full (n_total, 7) tensor (None on the other ranks, or when gather=False)."""
         import contextlib
+        if gather and self.sparse and self.world > 1:
+            return self._run_sparse()
         torch, dist = self.torch, self.dist
         mine = self.chunks[self.rank]
         pending = []
@@ -167,6 +241,8 @@ class ShardedFrame:
         for reqs in pending:
             for q in reqs:
                 q.wait()
+        if gather and self.rank == self.dst:
+            self.root_bytes = 4 * self.k * (self.n_total - (self.slabs[self.dst][1] - self.slabs[self.dst][0]))
         if self.cuda:
             for cs in self.compute_streams:
                 caller.wait_stream(cs)
