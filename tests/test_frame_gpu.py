@@ -148,10 +148,10 @@ def test_sparse_payload_moves_only_the_live_rays(gpu, cfg, devices, chunk):
         dense_bytes = sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices)))
         sparse = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD_SPARSE)
         again = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD_SPARSE, out=torch.full_like(sparse, 9.0))   # staging reuse
+        sparse_bytes = sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices)))   # (of the last render call)
+        info = [frame.lane_info(i) for i in range(len(devices))]
         rec = frame.render(n, ray_index_base=base, layout=FRAME_RECORDS)                                               # and another layout behind it
         torch.cuda.synchronize()
-        sparse_bytes = sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices)))
-        info = [frame.lane_info(i) for i in range(len(devices))]
     assert torch.equal(dense.view(torch.int32), ref7.view(torch.int32))
     assert torch.equal(sparse[live].view(torch.int32), ref7[live].view(torch.int32))
     assert bool((sparse[~live] == 0).all()) and int((~live).sum()) > 0 or cfg == "C4"
