@@ -5,7 +5,7 @@
 //           whole host precompute -- parse, focus, exit-pupil LUT, bokeh CDF -- plus the error paths;
 //   part 3 (when a HIP device is visible): zoic_frame_* over devices {0, 0, 0} -- update threads, host-render threads, chunked
 //          device render -- against one camera's result
-//   part 2 (when a HIP device is visible): 16 render threads hammer ONE camera with camera_create_ray / Arnold-layout /
+//   part 2 (when a HIP device is visible): 16 render threads hammer ONE camera with camera_create_ray / tile / Arnold-layout /
 //           host-buffer calls, the contract of zoic.cpp:1752; the results are checked against a serial replay.
 // Exit code 0 = clean; the sanitizer runtime turns any report into a non-zero exit.
 #include <atomic>
@@ -90,9 +90,32 @@ static void render_worker(zoic_camera *cam, int t, int calls, ThreadLog *log)
 {
     unsigned s = 12345u + 977u * static_cast<unsigned>(t);
     auto rnd = [&s]() { s = s * 1664525u + 1013904223u; return static_cast<float>(s >> 8) * (1.0f / 16777216.0f); };
+    // a tile of this render thread's own (zoic_tile_*: page-locked rows the resident kernel reads and writes in place)
+    zoic_tile *tile = nullptr;
+    CHECK(zoic_tile_create(cam, 2048, static_cast<uint16_t>(t), &tile) == ZOIC_OK);
     for (int i = 0; i < calls; ++i) {
         const float kind = rnd();
-        if (kind < 0.7f) {
+        if (kind < 0.12f && tile) {
+            // a bucket through the tile server: sometimes the tile's own arrays (submit, a per-sample call on the same slot in between,
+            // wait), sometimes the one-call form on pageable arrays (staged)
+            const uint32_t m = 1u + static_cast<uint32_t>(rnd() * 2047.0f);
+            const uint64_t base = 9000000ull * static_cast<unsigned>(t) + static_cast<unsigned>(i);
+            if (rnd() < 0.5f) {
+                zoic_camera_input *in = zoic_tile_inputs(tile);
+                for (uint32_t k = 0; k < m; ++k) in[k] = zoic_camera_input{2.0f * rnd() - 1.0f, (2.0f * rnd() - 1.0f) * 0.5625f, 0, 0, rnd(), rnd(), 0};
+                CHECK(zoic_tile_submit(tile, m, base) == ZOIC_OK);
+                (void)zoic_tile_done(tile);
+                CHECK(zoic_tile_wait(tile) == ZOIC_OK);
+                const zoic_camera_output *out = zoic_tile_outputs(tile);
+                for (uint32_t k = 0; k < m; k += 61) log->values.insert(log->values.end(), {out[k].dir.x, out[k].dir.z, out[k].weight[1], out[k].dOdy.y});
+            } else {
+                std::vector<zoic_camera_input> in(m);
+                std::vector<zoic_camera_output> out(m);
+                for (uint32_t k = 0; k < m; ++k) in[k] = zoic_camera_input{2.0f * rnd() - 1.0f, (2.0f * rnd() - 1.0f) * 0.5625f, 0, 0, rnd(), rnd(), 0};
+                CHECK(zoic_camera_create_rays_tile(cam, m, in.data(), out.data(), base, static_cast<uint16_t>(t)) == ZOIC_OK);
+                for (uint32_t k = 0; k < m; k += 61) log->values.insert(log->values.end(), {out[k].dir.x, out[k].dir.z, out[k].weight[1], out[k].dOdy.y});
+            }
+        } else if (kind < 0.7f) {
             zoic_camera_input in{2.0f * rnd() - 1.0f, (2.0f * rnd() - 1.0f) * 0.5625f, 0, 0, rnd(), rnd(), 0};
             zoic_camera_output out{};
             out.weight[0] = out.weight[1] = out.weight[2] = 1.0f;
@@ -118,6 +141,7 @@ static void render_worker(zoic_camera *cam, int t, int calls, ThreadLog *log)
             for (size_t k = 0; k < m; k += 211) log->values.insert(log->values.end(), {rays[k].dx, rays[k].oy, rays[k].weight, static_cast<float>(rays[k].flags)});
         }
     }
+    zoic_tile_destroy(tile);
 }
 
 static zoic_camera *render_camera()

@@ -19,7 +19,7 @@ SOURCES = ["capi.cpp", "frame.cpp", "lens_system.cpp", "kernels.hip", "kolb_pool
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(ROOT, "include", "zoic_amd.h")]
 
 # -ffp-contract=off: strict kernels and the host precompute must round exactly like the CPU oracle;
-# the fast kernel re-enables contraction locally with a pragma.  -fno-slp-vectorize: packing scalar f32 math into
+# the FAST arithmetic is written with explicit FMAs (csrc/fast_optics.hpp: contraction stays off there too).  -fno-slp-vectorize: packing scalar f32 math into
 # v_pk_* costs more in register shuffles than it saves on gfx950 (measured +8..20 % Mrays/s without it).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
