@@ -1,11 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python bench.py > gpurun_out/bench_r05_a.json 2> gpurun_out/bench_r05_a.err; tail -c 400 gpurun_out/bench_r05_a.err; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_r05_a.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline'])
-print(d.get('parity'))
-print(json.dumps(d['host_path'], indent=0)[:3000])
-for c in d.get('configs',[]): print(c['config'], c['mode'], c['value'], c.get('bound'), c.get('binding_frac'), c.get('flips'), c.get('rmse'))
-print(d.get('frame_api'))
-print(d.get('cpu_baseline'))
-PY
+LENS=zoic_amd/lenses/double_gauss_f2.0.dat
+timeout -k 10 600 python -m pytest tests/test_tile_gpu.py -x -q 2>&1 | tail -3
+for args in "1 256 1000 1 1 0" "1 1024 1000 1 1 0" "1 4096 1000 1 1 0" "1 4096 1000 0 1 0" "1 16384 300 1 1 0" "16 4096 500 1 1 0" "16 65536 60 1 1 0" "1 4096 1000 1 0 0"; do tools/native/tile_latency $LENS $args 2>&1 | tail -1 | cut -c1-220; done
+for t in tessar_f2.8 fisheye_muller_f4.0 petzval_f1.25; do echo $t; timeout -k 5 120 tools/native/tile_latency zoic_amd/lenses/$t.dat 1 4096 1000 1 1 0 | tail -1| cut -c1-220; done

@@ -340,6 +340,8 @@ void Mailbox::release()
             if (t[4])
                 std::fprintf(stderr, "worker batches since the slot wave saw the request: start avg %.2f us (max %.2f), flag written avg %.2f us (max %.2f)\n",
                              t[8] * 0.01 / t[4], t[9] * 0.01, t[10] * 0.01 / t[4], t[11] * 0.01);
+            if (t[4]) std::fprintf(stderr, "worker batches that started > 8 us after the request: %llu (mean batch index %.1f, %llu of them NOT the first batch after a wake-up); flagged > 25 us: %llu\n", t[12],
+                                   t[12] ? double(t[13]) / t[12] : 0.0, t[14], t[15]);
             for (int o = 0; o < 8; o += 4)
                 if (t[o])
                     std::fprintf(stderr, "tile timing (%s waves): %llu batches, input %.2f us, rays %.2f us, output %.2f us per batch\n", o ? "worker" : "slot", t[o],

@@ -367,6 +367,9 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
     uint32_t curSlot = kNoSlot, curPart = 0, partsTried = 0;   // the tile / ticket partition this wave draws from
     bool scanMask = false, leaving = false;                    // worker role: look at the work mask; the exit flag has been seen
     uint32_t idlePolls = 0;
+#ifdef ZOIC_TILE_TIMING
+    uint32_t lastWasHint = 0;
+#endif
     unsigned long long lastWake = 0;                           // worker role: the wake word last acted on (a posted one is never 0)
     while (watched) {
         if (wall_clock64() - start > kMailHardLifeTicks) break;   // safety net (never seen): the host reports a tile that is never answered
@@ -441,7 +444,10 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                         if (lane == 0) at = __hip_atomic_fetch_add(control + 8, wakeN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         at = first_lane(at);
                         const unsigned long long tag = (static_cast<unsigned long long>(static_cast<uint32_t>(now) | 1u) << 32) | slot;
-                        for (uint32_t i = lane; i < wakeN; i += 64u) store_dev(&st->wake[(at + i) % workerWaves].word, tag | (static_cast<unsigned long long>(i % parts) << 8));
+                        // the i-th woken worker is meant for batch i + 1: it starts on that batch's partition (partition 0 is one batch
+                        // short -- this wave's -- and every partition gets exactly as many workers as it has batches)
+                        const uint32_t per = (batches + parts - 1u) / parts;
+                        for (uint32_t i = lane; i < wakeN; i += 64u) store_dev(&st->wake[(at + i) % workerWaves].word, tag | (static_cast<unsigned long long>((i + 1u) / per) << 8));
                     }
                     ownJob = true; curPart = 0; partsTried = 0;
                 }
@@ -473,6 +479,9 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 lastWake = wk;
                 if ((wk >> 16) & 1ull) { leaving = true; scanMask = true; continue; }
                 curSlot = static_cast<uint32_t>(wk) & 63u; curPart = static_cast<uint32_t>(wk >> 8) & (kTileParts - 1u); partsTried = 0;
+#ifdef ZOIC_TILE_TIMING
+                lastWasHint = 2u;
+#endif
                 continue;
             }
             // the ticket and -- speculatively, in the same round trip -- the descriptor
@@ -520,6 +529,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         }
 #ifdef ZOIC_TILE_TIMING
         const unsigned long long tt0 = wall_clock64();
+        if (lastWasHint) --lastWasHint;   // 1: this batch is the first after a wake-up
 #endif
 
         // ---- the pass's samples: the slot's one sample in lane 0, or 64 consecutive rows of the tile --------------------------
@@ -629,6 +639,8 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             if (!slotRole) {
                 const unsigned long long tp = load_dev(reinterpret_cast<unsigned long long *>(st->jobs + jobSlot) + 6);
                 atomicAdd(&st->timing[8], tt0 - tp); atomicMax(&st->timing[9], tt0 - tp); atomicAdd(&st->timing[10], tt3 - tp); atomicMax(&st->timing[11], tt3 - tp);
+                if (tt0 - tp > 800ull) { atomicAdd(&st->timing[12], 1ull); atomicAdd(&st->timing[13], static_cast<unsigned long long>(batch)); if (lastWasHint == 0u) atomicAdd(&st->timing[14], 1ull); }
+                if (tt3 - tp > 2500ull) { atomicAdd(&st->timing[15], 1ull); }
             }
             atomicAdd(&st->timing[o], 1ull); atomicAdd(&st->timing[o + 1], tt1 - tt0); atomicAdd(&st->timing[o + 2], tt2 - tt1); atomicAdd(&st->timing[o + 3], tt3 - tt2);
         }
