@@ -720,6 +720,9 @@ def main():
                             compute_ms=strong["compute_ms"], root_ingest_gb_s=strong["root_ingest_gb_s"], root_ingest_frac=strong["root_ingest_frac"],
                             bit_identical_to_single_gpu=strong.get("bit_identical_to_single_gpu"), sub_launches_per_slab=strong["sub_launches_per_slab"],
                             chunk_mb=strong["chunk_mb"])
+                for k in ("root_bytes", "with_sparse_gather", "sparse_gather_ms", "root_bytes_sparse", "sparse_failed"):
+                    if k in strong:
+                        line[k] = strong[k]
                 line["config"]["parallelism"] = "ONE frame per step in %d ray-index slabs (dp%d), RCCL gather of the 28 B/ray payload to rank 0 included" % (world, world)
                 line["config"]["rays_per_gpu_per_step"] = n // world
             elif strong:
@@ -745,7 +748,8 @@ def main():
             if rank == 0:
                 finish_line("timed out after %d s behind the weak-scaling leg" % args.sharded_timeout)
             os._exit(3)
-        watchdog = threading.Timer(args.sharded_timeout, give_up)
+        # (rank 0 first: it holds the line; the other ranks give it 20 s to print before they leave)
+        watchdog = threading.Timer(args.sharded_timeout + (0 if rank == 0 else 20), give_up)
         watchdog.daemon = True
         watchdog.start()
         note = None

@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-LENS=zoic_amd/lenses/double_gauss_f2.0.dat
-timeout -k 10 600 python -m pytest tests/test_tile_gpu.py -x -q 2>&1 | tail -3
-for args in "1 256 1000 1 1 0" "1 1024 1000 1 1 0" "1 4096 1000 1 1 0" "1 4096 1000 0 1 0" "1 16384 300 1 1 0" "16 4096 500 1 1 0" "16 65536 60 1 1 0" "1 4096 1000 1 0 0"; do tools/native/tile_latency $LENS $args 2>&1 | tail -1 | cut -c1-220; done
-for t in tessar_f2.8 fisheye_muller_f4.0 petzval_f1.25; do echo $t; timeout -k 5 120 tools/native/tile_latency zoic_amd/lenses/$t.dat 1 4096 1000 1 1 0 | tail -1| cut -c1-220; done
+ZOIC_BENCH_SAME_GPU=1 timeout -k 10 1500 python bench.py --gpus 2 --steps 1 --warmup 1 --no-sharded --sharded-timeout 1200 > gpurun_out/bench_r05_rehearsal_2ranks_same_gpu.json 2> gpurun_out/rehearsal.err; echo "rehearsal rc=$?"; tail -c 300 gpurun_out/rehearsal.err; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_r05_rehearsal_2ranks_same_gpu.json').read().strip().splitlines()[-1])
+d.pop('notes',None); d.pop('roofline',None)
+print(json.dumps(d)[:2500])
+PY

@@ -159,7 +159,7 @@ class ShardedFrame:
                     for r in peers:
                         ra, rb = self.chunks[r][k]
                         bits, rows = bufs[r]
-                        live_mask = ((bits[:, None] >> torch.arange(8, device=self.device, dtype=torch.uint8)[None, :]) & 1).reshape(-1)[: rb - ra].bool()
+                        live_mask = ((bits.to(torch.int32)[:, None] // (2 ** torch.arange(8, device=self.device, dtype=torch.int32))[None, :]) % 2).reshape(-1)[: rb - ra].bool()
                         self.full[ra:rb][live_mask] = rows
                 elif rec is not None:
                     pay = rec[:, :self.k]
@@ -168,7 +168,7 @@ class ShardedFrame:
                     m = b - a
                     padded = torch.zeros(((m + 7) // 8) * 8, dtype=torch.uint8, device=self.device)
                     padded[:m] = live_mask.to(torch.uint8)
-                    bits = (padded.reshape(-1, 8) << torch.arange(8, device=self.device, dtype=torch.uint8)[None, :]).sum(1).to(torch.uint8)
+                    bits = (padded.reshape(-1, 8).to(torch.int32) * (2 ** torch.arange(8, device=self.device, dtype=torch.int32))[None, :]).sum(1).to(torch.uint8)
                     count = torch.tensor([rows.shape[0]], dtype=torch.int64, device=self.device)
                     for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, count, self.dst)]):
                         q.wait()
