@@ -415,6 +415,8 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
                    root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((world - 1) * XGMI_LINK_GBS), 3), root_bytes=into_root)
         # the gather with only the rays of weight != 0 on the wire (ShardedFrame(sparse=True): counts first, then bits + rows)
         try:
+            if dist.get_backend() != "nccl":   # the gloo rehearsal moves device tensors through the host at ~25 MB/s: one dense leg is rehearsal enough
+                raise RuntimeError("skipped: not an RCCL run")
             frame.sparse = True
             t_sparse = timed(True)
             ent.update(with_sparse_gather=round(n_total * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3), root_bytes_sparse=int(frame.root_bytes))
