@@ -90,6 +90,7 @@ def parse_args():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of one repetition of a CPU baseline leg")
+    ap.add_argument("--no-sparse-leg", action="store_true", help="N > 1: skip the sparse gather's timing (it runs last, behind everything else)")
     ap.add_argument("--no-single-process", action="store_true", help="N > 1: skip the zoic_frame_* measurement (rank 0 driving all devices)")
     ap.add_argument("--sharded-timeout", type=int, default=240, help="N > 1: seconds everything behind the weak-scaling leg (gathers included) may take before the line is printed with what has been measured")
     ap.add_argument("--gather-chunk-mb", type=int, default=0, help="payload MB per gather chunk (0: a quarter of a slab, at least 64 MB)")
@@ -358,7 +359,7 @@ def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, par
     return ent
 
 
-def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, steps, chunk_mb, precision="fast", warmup=1, ent=None):
+def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, steps, chunk_mb, precision="fast", warmup=1, ent=None, sparse_leg=False):
     """ONE frame of `cfg_name` in ray-index slabs over the ranks (north_star): compute-only and gather-inclusive
     rates, K timed steps each between barriers, max over ranks.  `ent` is filled as results arrive (a watchdog may print it)."""
     from zoic_amd.sharding import PAYLOAD_FLOATS, ShardedFrame
@@ -413,16 +414,6 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
         ingest = into_root * steps / t_gather / 1e9
         ent.update(with_gather=round(n_total * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3), chunk_mb=frame.chunk_bytes >> 20,
                    root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((world - 1) * XGMI_LINK_GBS), 3), root_bytes=into_root)
-        # the gather with only the rays of weight != 0 on the wire (ShardedFrame(sparse=True): counts first, then bits + rows)
-        try:
-            if dist.get_backend() != "nccl":   # the gloo rehearsal moves device tensors through the host at ~25 MB/s: one dense leg is rehearsal enough
-                raise RuntimeError("skipped: not an RCCL run")
-            frame.sparse = True
-            t_sparse = timed(True)
-            ent.update(with_sparse_gather=round(n_total * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3), root_bytes_sparse=int(frame.root_bytes))
-        except Exception as e:  # noqa: BLE001
-            ent["sparse_failed"] = str(e)[:120]
-        frame.sparse = False
         # rank 0 holds the gathered frame: a peer's chunk must equal what this GPU computes for the same global rays
         full = frame.run(gather=True)
         torch.cuda.synchronize()
@@ -431,6 +422,19 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
             s = cam.generate_samples(b - a, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=a)
             mine = cam.create_rays(s, ray_index_base=a)["rays"][:, :PAYLOAD_FLOATS]
             ent["bit_identical_to_single_gpu"] = bool(torch.equal(mine.contiguous().view(torch.int32), full[a:b].view(torch.int32)))
+        # LAST (everything above is safe if this leg misbehaves on its first meeting with real peers):
+        # the gather with only the rays of weight != 0 on the wire (ShardedFrame(sparse=True): counts first, then bits + rows)
+        try:
+            if not sparse_leg:
+                raise RuntimeError("skipped (--no-sparse-leg)")
+            if dist.get_backend() != "nccl":   # the gloo rehearsal moves device tensors through the host at ~25 MB/s: one dense leg is rehearsal enough
+                raise RuntimeError("skipped: not an RCCL run")
+            frame.sparse = True
+            t_sparse = timed(True)
+            ent.update(with_sparse_gather=round(n_total * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3), root_bytes_sparse=int(frame.root_bytes))
+        except Exception as e:  # noqa: BLE001
+            ent["sparse_failed"] = str(e)[:120]
+        frame.sparse = False
     cam.close()
     del samples, recs, frame
     torch.cuda.empty_cache()
@@ -474,11 +478,6 @@ def single_process_frame_entry(torch, cfg_name, precision, devices, steps, warmu
         ent.update(with_gather=round(n * steps / t_gather / 1e6, 1), gather_ms=round(t_gather / steps * 1e3, 3),
                    root_bytes=sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices))),
                    peer_access=[int(frame.lane_info(i)["peer_access_to_root"] and frame.lane_info(i)["peer_access_from_root"]) for i in range(len(devices))])
-        # the same gather with only the rays of weight != 0 on the wire (ZOIC_FRAME_PAYLOAD_SPARSE)
-        t_sparse = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD_SPARSE))
-        ent.update(with_sparse_gather=round(n * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3),
-                   root_bytes_sparse=sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices))))
-        t_gather = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD))   # (the dense rows again: what the bit-identity check below reads)
         if len(set(devices)) > 1:   # (a device listed twice copies to itself: no link involved)
             ingest = into_root * steps / t_gather / 1e9
             ent.update(root_ingest_gb_s=round(ingest, 1), root_ingest_frac=round(ingest / ((len(devices) - 1) * XGMI_LINK_GBS), 3))
@@ -494,6 +493,10 @@ def single_process_frame_entry(torch, cfg_name, precision, devices, steps, warmu
         ent["bit_identical_to_single_gpu"] = same
         cam.close()
         del ref, s
+        # the same gather with only the rays of weight != 0 on the wire (ZOIC_FRAME_PAYLOAD_SPARSE)
+        t_sparse = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD_SPARSE))
+        ent.update(with_sparse_gather=round(n * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3),
+                   root_bytes_sparse=sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices))))
     frame.close()
     del out
     torch.cuda.empty_cache()
@@ -756,6 +759,10 @@ def main():
         watchdog.start()
         note = None
         try:
+            # north_star's number FIRST (dense RCCL gather); then the single-process frame; then C4 / C5; the RCCL sparse gather (C5: the frame
+            # it was built for) is the LAST thing the run does -- nothing above is lost if it misbehaves on its first meeting with real peers
+            if not args.rays:
+                sharded_frame_entry(torch, dist, args.config, dev, rank, world, local_rank, args.steps, args.gather_chunk_mb, args.precision, args.warmup, strong)
             # rank 0 alone drives all N devices through the C-ABI (no RCCL involved); the other ranks wait on the rendezvous store,
             # not in a collective -- a barrier kernel spinning on their GPUs would share them with rank 0's launches
             if not args.no_single_process and not args.rays:
@@ -773,12 +780,10 @@ def main():
                 else:
                     store.wait(["zoic_spf_done"], datetime.timedelta(seconds=args.sharded_timeout))
                 rank_barrier(dist, local_rank)
-            if not args.rays:
-                sharded_frame_entry(torch, dist, args.config, dev, rank, world, local_rank, args.steps, args.gather_chunk_mb, args.precision, args.warmup, strong)
             if not args.no_sharded:
                 for cname, st in (("C4", 5), ("C5", 2)):
                     if cname != args.config:
-                        e = sharded_frame_entry(torch, dist, cname, dev, rank, world, local_rank, st, args.gather_chunk_mb)
+                        e = sharded_frame_entry(torch, dist, cname, dev, rank, world, local_rank, st, args.gather_chunk_mb, sparse_leg=cname == "C5" and not args.no_sparse_leg)
                         if rank == 0:
                             sharded.append(e)
         except Exception as e:  # noqa: BLE001 -- reported in the line; the weak leg stands
