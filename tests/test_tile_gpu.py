@@ -252,3 +252,49 @@ def test_the_cpp_tile_buffer_accumulate_flush_serve(gpu, precision):
                                "-lzoic_amd", "-lpthread", "-Wl,-rpath," + os.path.join(root, "zoic_amd")])
     out = subprocess.run([exe, os.path.join(root, "zoic_amd", "lenses", "tessar_f2.8.dat"), str(precision)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "tile_buffer_test OK" in out.stdout, (out.stdout[-300:], out.stderr[-600:])
+
+
+def test_tile_fuzz_random_cameras_hostile_samples_both_modes(gpu):
+    """Machine-made cameras (every shipped prescription with a stop, both lens models, LUT on / off, bokeh images that are not square,
+    exposure, optical vignetting) and samples nobody should send (+-0, 0.5, 1.0, denormals, 1e30, +-inf, NaN) through tiles of ragged
+    sizes: every row equals zoic_create_rays_arnold's, bit for bit (NaN == NaN), in STRICT and in FAST, counters included."""
+    import os
+    from hypothesis import given, settings, HealthCheck, strategies as st
+    from zoic_amd import RAYTRACED, THINLENS, lens_path
+    lenses = ["double_gauss_f2.0.dat", "tessar_f2.8.dat", "fisheye_muller_f4.0.dat", "petzval_f1.25.dat", "triplet_f2.5.dat", "mori_f2.8.dat"]
+    special = np.array([0.0, -0.0, 0.5, 1.0, -1.0, 0.99999994, 1e-40, 1e30, np.inf, -np.inf, np.nan, 2.0, -3.0], np.float32)
+
+    @settings(max_examples=int(os.environ.get("ZOIC_FUZZ_EXAMPLES_TILE", os.environ.get("ZOIC_FUZZ_EXAMPLES", "40"))), deadline=None,
+              suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.sampled_from(lenses), st.sampled_from([RAYTRACED, RAYTRACED, RAYTRACED, THINLENS]), st.booleans(), st.booleans(), st.booleans(),
+           st.floats(2.0, 12.0, width=32), st.floats(1.25, 11.0, width=32), st.floats(1.0, 7.5, width=32), st.integers(0, 2 ** 16), st.floats(0.0, 0.95),
+           st.sampled_from([0.0, 0.0, 3.0]), st.sampled_from([0.0, 0.7, -1.5]))
+    def run(lens, model, lut, image, fast, focal, fstop, sensor_w, seed, where, ov, exposure):
+        rs = np.random.RandomState(seed)
+        p = dict(lensModel=model, lensDataPath=lens_path(lens), focalLength=focal, fStop=fstop, focalDistance=100.0, sensorWidth=sensor_w,
+                 sensorHeight=sensor_w / 1.5, kolbSamplingLUT=lut, useImage=image, bokehPath="mem:tilefuzz%d" % seed, opticalVignettingDistance=ov,
+                 opticalVignettingRadius=0.8, exposureControl=exposure)
+        cam = ZoicCamera(0)
+        if image:
+            h, w = int(rs.randint(2, 40)), int(rs.randint(2, 40))
+            cam.set_bokeh_image(np.repeat(rs.rand(h, w).astype(np.float32)[:, :, None], 3, axis=2))
+        try:
+            cam.update(**p)
+        except ZoicError:
+            cam.close()
+            return
+        cam.set_precision(PRECISION_FAST if fast else PRECISION_STRICT)
+        n = int(rs.randint(1, 3000))
+        a, _s, base = inputs_of("C2", n, where)
+        hostile = rs.rand(n, 7) < 0.01
+        a[hostile] = special[rs.randint(len(special), size=int(hostile.sum()))]
+        cam.reset_counters()
+        ref = cam.create_rays_arnold(a, ray_index_base=base)
+        c_ref = cam.counters()
+        cam.reset_counters()
+        out = cam.create_rays_tile(a, ray_index_base=base, tid=int(rs.randint(0, 200)))
+        c_out = cam.counters()
+        assert same_rows(out, ref), (p, fast, n, np.nonzero((bits(out) != bits(ref)).any(1))[0][:5])
+        assert c_ref == c_out, (p, fast, c_ref, c_out)
+        cam.close()
+    run()

@@ -1346,7 +1346,7 @@ static zoic_status tile_post_locked(zoic_camera *cam, unsigned slot, uint32_t n,
     q->inLo = static_cast<uint32_t>(dIn); q->inHi = static_cast<uint32_t>(dIn >> 32); q->n = n;
     std::atomic_thread_fence(std::memory_order_release);   // the caller's input rows and the words above, then the numbers
     q->seq2 = seq; q->seq1 = seq; q->seq0 = seq;
-    const uint32_t perBatch = cam->params.p.lensModel == ZOIC_THINLENS ? kTileRaysThin : kTileRaysRaytraced;   // (mailbox.hip)
+    const uint32_t perBatch = tile_rays_per_batch(cam->params.p.lensModel == ZOIC_THINLENS, n);   // (mailbox.hpp: the kernel's rule)
     M.tileSeq[slot] = seq; M.tileBatches[slot] = (n + perBatch - 1u) / perBatch; M.tileSeen[slot] = 0u;
     *seqOut = seq;
     return ZOIC_OK;

@@ -104,7 +104,7 @@ __device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have
 // once the rounds are over.  Every try is evaluated by the same device functions as everywhere else in the library: same bits as
 // the batch kernels and as the reference's loop order (tests/test_tile_gpu.py, tests/test_boundary_gpu.py).
 constexpr uint32_t kTileStageWords = 512;   // LDS stage per wave (THINLENS: 64 x 7 input dwords, then 64 x 8 record dwords)
-constexpr uint32_t kKolbBatch = 16;        // rays per wave pass
+constexpr uint32_t kKolbBatch = kTileRaysRaytraced;   // rays per wave pass (mailbox.hpp)
 // LDS stage of a wave (kTileStageWords dwords): [0, 128) the finished records, 8 dwords per ray (what the output stage reads);
 // [128, 448) the rays' state, 20 dwords each; [384, 496) the batch's input rows on arrival (dead before the state is written);
 // [448, 452) a round's outcome masks
@@ -323,7 +323,7 @@ template <int MODEL, int MODE>
 __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, const ThinTable Th, const BokehTables B, char *mapped,
                                                              MailDeviceState *st, DeviceCounters *counters, uint32_t ldsWords, uint32_t totalWaves)
 {
-    constexpr uint32_t kRays = MODEL == 0 ? 64u : kKolbBatch;   // samples per batch of a tile: RAYTRACED spends at least four lanes on a ray (kolb_wave_rays)
+    constexpr uint32_t kRays = MODEL == 0 ? 64u : kKolbBatch;   // the LARGEST batch of a tile (tile_rays_per_batch, mailbox.hpp: small RAYTRACED tiles are cut into half batches)
     if (threadIdx.x < kLutEntries) {
         zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
         zoicDynLds[2 * threadIdx.x + 1] = T.lutCentroidX[threadIdx.x];
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         uint32_t work = 0;      // 1: one sample (slot role), 2: one 64-sample batch of a tile
         float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         Rng rng{1u, 2u, 3u, 4u};
-        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobSeq = 0;
+        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobSeq = 0, jobRays = kRays;
         unsigned long long jobIn = 0, jobOut = 0, jobBase = 0;
         if (slotRole && !ownJob) {
             u32x4 line, ctl;   // ctl: the launch's control block = {exit flag, waves out, time of the last call (lo, hi)}
@@ -414,19 +414,20 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 jobSeq = seq; jobSlot = slot; batch = 0;
                 if (jobN == 0u) continue;       // (the host never posts an empty tile)
                 work = 2;                       // batch 0 is this wave's, straight from the request: a tile of one batch involves nobody else
-                if (jobN > kRays) {
+                jobRays = tile_rays_per_batch(MODEL == 0, jobN);
+                if (jobN > jobRays) {
                     // the rest is POSTED for the workers: descriptor (three 16-byte chunks, each ending in the tile's number, like a
                     // request line), the ticket counters (partition 0 starts behind this wave's batch), the slot's bit; then as many
                     // workers are woken as there are batches left, each with the partition it should start on.  Whoever draws a ticket
                     // of generation `seq` finds this descriptor.
-                    const uint32_t batches = (jobN + kRays - 1u) / kRays;
+                    const uint32_t batches = (jobN + jobRays - 1u) / jobRays;
                     uint32_t parts = batches / 8u;   // about eight batches per counter: same-address atomics queue up (~0.1 us each across the XCDs)
                     parts = parts < 1u ? 1u : (parts > kTileParts ? kTileParts : parts);
                     if (lane == 0) {
                         uint4 *J = reinterpret_cast<uint4 *>(st->jobs + slot);
                         store_dev4(J, make_uint4(lane_word(line.x, 0), lane_word(line.y, 0), jobN, seq));
                         store_dev4(J + 1, make_uint4(lane_word(line.x, 1), lane_word(line.y, 1), lane_word(line.z, 1), seq));
-                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts, seq));
+                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts | (jobRays << 16), seq));
                         store_dev(&st->tickets[slot].partsLeft, parts);
 #ifdef ZOIC_TILE_TIMING
                         store_dev(reinterpret_cast<unsigned long long *>(st->jobs + slot) + 6, static_cast<unsigned long long>(now));
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 load_dev4x3(J, c0, c1, c2);
             }
-            const uint32_t batches = first_lane(c2.y), parts = first_lane(c2.z);
+            const uint32_t batches = first_lane(c2.y), parts = first_lane(c2.z) & 0xffffu;
+            jobRays = first_lane(c2.z) >> 16;
             const bool sameTile = first_lane(c0.w) == gen && first_lane(c1.w) == gen && first_lane(c2.w) == gen;
             const uint32_t per = sameTile ? (batches + parts - 1u) / parts : 1u;
             const uint32_t lo = curPart * per, hi = lo + per < batches ? lo + per : batches;   // the partition's batches
@@ -539,8 +541,8 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         uint32_t first = 0, cnt = 1;
         unsigned long long rayBase = 0;
         if (work == 2u) {
-            first = batch * kRays;
-            cnt = jobN - first < kRays ? jobN - first : kRays;
+            first = batch * jobRays;
+            cnt = jobN - first < jobRays ? jobN - first : jobRays;
             // AtCameraInput rows are 7 dwords (sx sy dsx dsy lensx lensy relative_time): lane l fetches dword k * 64 + l of the batch's
             // 7 * cnt -- whole 256-byte runs per instruction across PCIe -- and picks its row out of LDS
             const uint32_t *src = reinterpret_cast<const uint32_t *>(jobIn) + static_cast<size_t>(first) * 7u;

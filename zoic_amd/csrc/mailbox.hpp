@@ -48,8 +48,23 @@ static_assert(sizeof(MailRequest) == 64 && sizeof(MailTileRequest) == 64 && size
 // byte offsets into the mapped allocation
 // (tile flags: one word per 64-sample batch of a slot's tile -- the tile's sequence number once the batch's rows are complete, written
 // by the wave that made them behind a system-scope release; the render thread waits for all of its tile's)
-constexpr uint32_t kTileRaysRaytraced = 16, kTileRaysThin = 64;   // samples per batch of a tile (mailbox.hip: RAYTRACED spends four lanes on a ray)
-constexpr uint32_t kTileMaxBatches = kTileMaxSamples / kTileRaysRaytraced;
+#ifndef ZOIC_TILE_RAYS
+#define ZOIC_TILE_RAYS 16   // rays a resident wave holds at once (RAYTRACED): 64 / this lanes per ray in the first round
+#endif
+constexpr uint32_t kTileRaysRaytraced = ZOIC_TILE_RAYS, kTileRaysThin = 64;
+// Samples per batch of an n-sample tile (host and kernel agree on this; the descriptor carries it).  A RAYTRACED wave shares its 64 lanes
+// among the rays it holds, so half a batch of rays finishes in fewer rounds -- and serves half the rays per wave pass.  Measured
+// [MI355X, profiles/ab_r05/tile_latency_v6.txt]: 8 instead of 16 rays for tiles up to 8192 samples: double Gauss 4096 samples 36.7 ->
+// 34.2 us (STRICT 41 -> 35), but TESSAR / fisheye / PETZVAL 1-2 us SLOWER, a 16-sample tile 14 -> 16.4 us (two batches), 16 threads x
+// 4096 samples 212 -> 141 Mrays/s; 8 rays throughout: 16 threads x 65536 samples 479 -> 280 Mrays/s.  One size, 16.
+#if defined(__HIPCC__) || defined(__cplusplus)
+inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+uint32_t tile_rays_per_batch(bool thinLens, uint32_t n) { (void)n; return thinLens ? kTileRaysThin : kTileRaysRaytraced; }
+#endif   // samples per batch of a tile (mailbox.hip: RAYTRACED spends four lanes on a ray)
+constexpr uint32_t kTileMaxBatches = kTileMaxSamples / kTileRaysRaytraced;   // (>= 8192 / (kTileRaysRaytraced / 2))
 constexpr size_t kMailRequestsOffset = 64, kMailRepliesOffset = kMailRequestsOffset + 64 * kMailSlots,
                  kMailTileFlagsOffset = kMailRepliesOffset + 64 * kMailSlots, kMailBytes = kMailTileFlagsOffset + 4u * kTileMaxBatches * kMailSlots;
 
@@ -60,7 +75,7 @@ constexpr uint32_t kTileMaxWorkerWaves = 1024;   // wake lines (kTileWorkerGroup
 struct alignas(64) TileJob {                  // three 16-byte chunks, each ending in the tile's sequence number (like a request line):
     uint32_t inLo, inHi, n, seq0;             // written by the slot's wave, read -- in the same round trip as the ticket -- by whoever
     uint32_t outLo, outHi, baseLo, seq1;      // draws one; a descriptor whose three numbers equal the ticket's generation is that tile's
-    uint32_t baseHi, batches, parts, seq2;    // parts: ticket partitions in use (1 ... kTileParts); partition p hands out batches
+    uint32_t baseHi, batches, parts, seq2;    // parts: ticket partitions in use (1 ... kTileParts) | samples per batch << 16; partition p hands out batches
     uint32_t fill[4];                         //        [p * per, min((p + 1) * per, batches)), per = ceil(batches / parts)
 };
 struct alignas(64) TileCounter { unsigned long long next; uint32_t pad[14]; };   // (generation << 32) | next batch of the partition
