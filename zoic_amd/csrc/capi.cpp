@@ -335,8 +335,9 @@ void Mailbox::release()
     (void)stop();
 #ifdef ZOIC_TILE_TIMING   // (tools/: -DZOIC_TILE_TIMING builds print where a tile batch's time went when the camera is destroyed)
     if (dState) {
-        unsigned long long t[16];
+        unsigned long long t[32];
         if (hipMemcpy(t, dState->timing, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (t[4]) std::fprintf(stderr, "rays per batch < 8 / 12 / 16 / 24 / more us: %llu %llu %llu %llu %llu; start < 6 / 8 / 12 / more us after the request: %llu %llu %llu %llu\n", t[16], t[17], t[18], t[19], t[20], t[24], t[25], t[26], t[27]);
             if (t[4])
                 std::fprintf(stderr, "worker batches since the slot wave saw the request: start avg %.2f us (max %.2f), flag written avg %.2f us (max %.2f)\n",
                              t[8] * 0.01 / t[4], t[9] * 0.01, t[10] * 0.01 / t[4], t[11] * 0.01);

@@ -643,6 +643,9 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 atomicAdd(&st->timing[8], tt0 - tp); atomicMax(&st->timing[9], tt0 - tp); atomicAdd(&st->timing[10], tt3 - tp); atomicMax(&st->timing[11], tt3 - tp);
                 if (tt0 - tp > 800ull) { atomicAdd(&st->timing[12], 1ull); atomicAdd(&st->timing[13], static_cast<unsigned long long>(batch)); if (lastWasHint == 0u) atomicAdd(&st->timing[14], 1ull); }
                 if (tt3 - tp > 2500ull) { atomicAdd(&st->timing[15], 1ull); }
+                const unsigned long long rt = tt2 - tt1, stt = tt0 - tp;   // histograms: the rays' time, the start's delay
+                atomicAdd(&st->timing[16 + (rt < 800ull ? 0 : rt < 1200ull ? 1 : rt < 1600ull ? 2 : rt < 2400ull ? 3 : 4)], 1ull);
+                atomicAdd(&st->timing[24 + (stt < 600ull ? 0 : stt < 800ull ? 1 : stt < 1200ull ? 2 : 3)], 1ull);
             }
             atomicAdd(&st->timing[o], 1ull); atomicAdd(&st->timing[o + 1], tt1 - tt0); atomicAdd(&st->timing[o + 2], tt2 - tt1); atomicAdd(&st->timing[o + 3], tt3 - tt2);
         }

@@ -92,7 +92,7 @@ struct MailDeviceState {
     TileJob jobs[kMailSlots];
     TileTickets tickets[kMailSlots];
     TileWake wake[kTileMaxWorkerWaves];
-    unsigned long long timing[16];            // -DZOIC_TILE_TIMING builds only: 10 ns ticks per region of a batch, summed over all waves (tools/)
+    unsigned long long timing[32];            // -DZOIC_TILE_TIMING builds only: 10 ns ticks per region of a batch, summed over all waves (tools/)
 };
 
 int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, void *d_mapped,
