@@ -13,8 +13,8 @@
 //     tile.wait();
 //     for (i : bucket) tile.serve(i, output);                // exactly what camera_create_ray would have written into `output`
 //
-// A flushed bucket of 4096 samples is answered in ~15 us and 16 threads x 65536-sample buckets run at the PCIe rate of the
-// 84-byte AtCameraOutput rows (bench.py host_path.tile); the per-sample callback costs ~7 us per SAMPLE.  Rays are those of
+// A flushed bucket of 4096 samples is answered in ~35 us (thin lens ~18) and 16 threads x 65536-sample buckets run at the PCIe rate of
+// the 84-byte AtCameraOutput rows (bench.py host_path.tile: ~480 Mrays/s); the per-sample callback costs ~10 us per SAMPLE.  Rays are those of
 // zoic_create_rays_arnold bit for bit: sample i of the bucket draws its retries from the stream keyed by first_ray_index + i, so a
 // frame does not depend on which thread rendered which bucket (the reference's single global stream makes it depend on thread
 // timing, zoic.cpp:648).
