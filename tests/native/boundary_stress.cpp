@@ -95,10 +95,10 @@ static void render_worker(zoic_camera *cam, int t, int calls, ThreadLog *log)
     CHECK(zoic_tile_create(cam, 2048, static_cast<uint16_t>(t), &tile) == ZOIC_OK);
     for (int i = 0; i < calls; ++i) {
         const float kind = rnd();
-        if (kind < 0.12f && tile) {
+        if (kind < 0.06f && tile) {
             // a bucket through the tile server: sometimes the tile's own arrays (submit, a per-sample call on the same slot in between,
             // wait), sometimes the one-call form on pageable arrays (staged)
-            const uint32_t m = 1u + static_cast<uint32_t>(rnd() * 2047.0f);
+            const uint32_t m = 1u + static_cast<uint32_t>(rnd() * 1023.0f);
             const uint64_t base = 9000000ull * static_cast<unsigned>(t) + static_cast<unsigned>(i);
             if (rnd() < 0.5f) {
                 zoic_camera_input *in = zoic_tile_inputs(tile);
