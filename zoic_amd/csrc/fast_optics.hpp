@@ -270,7 +270,12 @@ __device__ __forceinline__ bool trace_lens_fast_rolled_from(FastSurfaceTable sur
 // finish dead get their reference partial state from trace_lens_fast_rolled).  tirMask: lanes that were totally reflected.
 // GUARD (decision-safe mode): unsureMask collects the lanes still alive at a guarded interface whose clip decision lies inside
 // the guard band.
-template <int NS, bool GUARD = false>
+// KEEP (the resident tile workers, mailbox.hip): a lane that dies keeps the PARTIAL state the branchy trace leaves on the same exit -- clipped:
+// (o, u) as they arrived at that interface; totally reflected: o advanced to the hit, u as it arrived; d = the raw direction if the
+// ray never got through a refraction, the last refracted unit direction otherwise -- so that a ray that finishes failed needs no second,
+// branchy trace (a lone wave waits for its chain of dependent instructions: six v_cndmask per interface off that chain cost it nothing,
+// a second trace costs a whole round).  The arithmetic per interface is the same FastHit / fast_refract: same bits.
+template <int NS, bool GUARD = false, bool KEEP = false>
 __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTable surf, V3 &o, V3 &d, unsigned long long alive0,
                                                                    unsigned long long &tirMask, unsigned long long &unsureMask)
 {
@@ -280,6 +285,7 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
     float oAxis2 = fast_axis2(o);
     unsigned long long alive = alive0, tirSeen = 0ull, unsure = 0ull;   // alive0: lanes without a candidate ride along dead
     unsigned long long nanRays = 0ull;                                  // candidates that arrived as NaN: they "pass" everything
+    unsigned long long refracted = 0ull;                                // KEEP: lanes that got through interface 0's refraction
     // The table words of interface i + 1 are requested BEFORE interface i is evaluated (scalar loads return out of order, so
     // the only wait there is is lgkmcnt(0): `surface_arrived` takes it at the end of interface i, a whole interface -- ~30 VALU --
     // after the request; the sched_barrier keeps the scheduler from sinking the request towards its use).  Loading at the use
@@ -302,17 +308,34 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
             clipped = ~__ballot(h.h2 <= S.housingLo);
             unsure |= alive & clipped & __ballot(h.h2 <= S.housingHi);
         } else clipped = ~__ballot(h.h2 <= S.housing2);   // the stop's housing2 includes the user aperture
+        if constexpr (KEEP) {
+            // a NaN ray is clipped nowhere (the branchy trace: !(h2 <= housing2) && !is_nan_ray): it stays alive and its state goes NaN
+            clipped &= ~nanRays;
+            alive &= ~clipped;
+            const bool through = __builtin_amdgcn_inverse_ballot_w64(alive);
+            o = V3{through ? h.hit.x : o.x, through ? h.hit.y : o.y, through ? h.hit.z : o.z};
+            oAxis2 = h.h2;
+            V3 un = u;
+            const unsigned long long tirHere = __ballot(fast_refract(S, h, un) < 0.0f);
+            tirSeen |= alive & tirHere;
+            alive &= ~tirHere;
+            const bool bent = __builtin_amdgcn_inverse_ballot_w64(alive);
+            u = V3{bent ? un.x : u.x, bent ? un.y : u.y, bent ? un.z : u.z};
+            if (i == 0) refracted = alive;
+        } else {
         o = h.hit;
         oAxis2 = h.h2;
         const unsigned long long tirHere = __ballot(fast_refract(S, h, u) < 0.0f);
         alive &= ~clipped;
         tirSeen |= alive & tirHere;                      // counted only by rays that reached the refraction
         alive &= ~tirHere;
+        }
         if constexpr (ZOIC_TRACE_PREFETCH != 0) { if (i + 1 < NS) surface_arrived(Sn); S = Sn; }   // ... and is waited for here, in the same block
         else if (i + 1 < NS) S = load_surface<GUARD && (ZOIC_GUARD_PIN != 0)>(surf, i + 1);
     }
     tirMask = tirSeen;
     unsureMask = unsure;
+    if constexpr (KEEP) { if (__builtin_amdgcn_inverse_ballot_w64(refracted)) d = u; return alive; }
     d = u;
     return alive | (alive0 & nanRays);
 }

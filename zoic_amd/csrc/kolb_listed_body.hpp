@@ -111,61 +111,127 @@ __device__ __forceinline__ bool listed_strict_try_pred(const KolbTable &T, V3 &o
     return ok;
 }
 
-// The rule above for ONE ray, sequentially (the per-sample mailbox kernel; the batch kernels below evaluate the same tries with
-// the same device functions, 64 rays or 16 tries at a time).  rng: the ray's retry stream at its first draw.
-struct ListedRay { V3 o, d; float w; uint32_t tries, lutMiss, tir; };
-__device__ __forceinline__ ListedRay listed_one_ray(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds, float4 s, Rng rng)
+// The tries of ONE listed ray side by side in the G lanes of a group (round 3's listed_short; the rule per try is the one above):
+// lane j of the group evaluates try k = G * round + j.  The tries of a ray are independent given its retry stream (try k >= 1 uses
+// draws 2(k-1), 2(k-1)+1); the first success in try order wins and TIR bumps count for the tries before it only (try 26 hands out its
+// state with weight 0 whether it got through or not, zoic.cpp:1927 / 1951).  Shared by the listed kernel's short lists (G fixed per
+// launch) and by the resident tile workers (mailbox.hip: G = the lanes a wave can spare per listed ray of its batch).
+//   rng      : this lane's copy of the ray's retry stream AT ITS TRY'S DRAWS (the caller steps lane j over j - 1 pairs before round 0;
+//              stepped over G - 1 pairs here for the next round)
+//   shift    : the group's first lane (its lanes are shift ... shift + G - 1)
+//   done     : the ray is finished (or the group holds none); returns the new value
+//   emit     : this lane holds the ray's final state -> (oOut, dOut, wOut, flagsOut) = the record's fields (negated, zoic.cpp:1960-1961)
+template <int NS>
+__device__ __forceinline__ bool listed_group_round(const KolbTable &T, const BokehTables &B, const float *bokehLds, const float4 &s, const RaySetup &rs,
+                                                   bool deadPixel, Rng &rng, uint32_t G, uint32_t j, uint32_t shift, uint32_t round, bool done,
+                                                   bool &emit, V3 &oOut, V3 &dOut, float &wOut, uint32_t &flagsOut, uint32_t &succ, uint32_t &vign, uint32_t &tir)
 {
-    ListedRay r;
-    const RaySetup rs = setup_ray<true>(T, lutLds, s.x, s.y);
-    r.lutMiss = rs.flags & 1u; r.tir = 0; r.tries = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t kOutTries = static_cast<uint32_t>(kMaxTries) + 1u;
     const V3 o0{rs.o0x, rs.o0y, T.originShift};
-    V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
-    if (!T.useLUT) r.d = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};
-    else {                                                    // zoic.cpp:1913-1924: x-only translation on the first sample
-        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
-        lens.x += rs.translation;
-        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
-        r.d = V3{rx - o0.x, ry - o0.y, T.dirZ};
-    }
-    r.o = o0;
-    bool ok = listed_strict_try(T, r.o, r.d, r.tir);
-    // a dead pixel's 26 retries repeat its first try bit for bit (kolb_pool_body.hpp): try 0's STRICT state stands, as in pass A of the
-    // long lists below -- a listed ray's bits do not depend on which of the three evaluators it met
-    if (!ok && rs.dead) {
-        const bool plainSample = (s.z >= 0.0f) & (s.z < 1.0f) & (s.w >= 0.0f) & (s.w < 1.0f) & !((s.z == 0.5f) & (s.w == 0.5f));
-        const V2 l0 = lens_sample<true>(T, B, bokehLds, s.z, s.w);
-        if (plainSample || ((fabsf(l0.x) <= 3.0e38f) && (fabsf(l0.y) <= 3.0e38f))) {
-            r.tir += r.tir * (static_cast<uint32_t>(kMaxTries) + 1u);
-            r.tries = static_cast<uint32_t>(kMaxTries) + 1u;
+    const uint32_t k = G * round + j;                                // this lane's try: 0 = the sample's own lens point, k = tries
+    const bool valid = !done && k <= kOutTries;
+    V3 o = o0, d{0.0f, 0.0f, 1.0f};
+    uint32_t tirTry = 0;
+    bool ok = false, unsure = false;
+    float u = 0.0f, v = 0.0f;
+    emit = false;
+    // every lane's direction first; then ONE FAST-guarded trace for the tries k >= 1 of the whole wave -- the predicated trace of
+    // the long-list path, so that a ray's bits do not depend on the path (one arithmetic, written with explicit FMAs: fast_optics.hpp) --
+    // and the reference's arithmetic for try 0 and for the tries that were too close to call
+    if (valid) {
+        if (k == 0u) {
+            V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
+            if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
+            else {                                                    // zoic.cpp:1913-1924: x-only translation
+                lens.x *= rs.maxScale; lens.y *= rs.maxScale;
+                lens.x += rs.translation;
+                const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
+                d = V3{rx - o.x, ry - o.y, T.dirZ};
+            }
+        } else {
+            u = rng_unit(xor128(rng));                                // zoic.cpp:1930
+            v = rng_unit(xor128(rng));
+            d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
         }
     }
-    while (!ok && r.tries <= static_cast<uint32_t>(kMaxTries)) {      // zoic.cpp:1927
-        const float u = rng_unit(xor128(rng));                        // zoic.cpp:1930
-        const float v = rng_unit(xor128(rng));
-        ++r.tries;
-        r.o = o0;
-        r.d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-        uint32_t tirTry = 0;
-        bool unsure = false;
-        ok = trace_lens_fast_rolled(T, r.o, r.d, tirTry, &unsure);
-        if (unsure) {
-            r.o = o0; tirTry = 0;
-            r.d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-            ok = listed_strict_try(T, r.o, r.d, tirTry);
+    const bool fastTry = valid && k != 0u;
+    if constexpr (NS > 0) {
+        const unsigned long long fastMask = __ballot(fastTry);
+        if (fastMask != 0ull) {
+            // the search's interface-0 test first, exactly as a B pass takes it (a try that dies there leaves (o, d) untouched)
+            bool near0 = false;
+            const bool pass0 = interface0_clear_fast<true>(load_surface<false>(kernarg_fast_surfaces(), 0), o, d, near0);
+            const bool cand = fastTry && pass0 && !near0;
+            unsure = fastTry && near0;
+            unsigned long long tirMask, unsureMask;
+            V3 ot = o, dt = d;
+            const unsigned long long alive = trace_lens_fast_pred<NS, true>(kernarg_fast_surfaces(), ot, dt, __ballot(cand), tirMask, unsureMask);
+            if (cand) {
+                ok = mask_bit(alive, lane);
+                tirTry = mask_bit(tirMask, lane) ? 1u : 0u;
+                unsure |= mask_bit(unsureMask, lane);
+                if (ok) { o = ot; d = dt; }
+                else if (!unsure && k == kOutTries) {   // only try 26's partial state is ever handed out
+                    uint32_t ignored = 0;
+                    (void)trace_lens_fast_rolled(T, o, d, ignored);
+                }
+            }
         }
-        r.tir += tirTry;
+    } else if (fastTry) ok = trace_lens_fast_rolled(T, o, d, tirTry, &unsure);
+    if (valid && (k == 0u || unsure)) {   // the reference's arithmetic: try 0, and a try too close to call (same draws)
+        o = o0; tirTry = 0;
+        if (k != 0u) d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
+        ok = listed_strict_try(T, o, d, tirTry);
     }
-    r.w = (r.tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;   // zoic.cpp:1951-1957: try 26 hands out its state with weight 0 whatever it did
-    if (T.exposureOn) r.w *= T.exposureMul;                             // zoic.cpp:1981-1987
-    return r;
+    // the next try of this lane, k + G, starts at draw 2 (k + G - 1): G - 1 pairs past where this try ended (2 k; try 0 drew nothing)
+    for (uint32_t a = 0; a + 1u < G; ++a) { (void)xor128(rng); (void)xor128(rng); }
+    // the group's decision, in try order
+    const unsigned long long okAll = __ballot(valid && ok);
+    const uint32_t groupBits = G >= 32u ? 0xffffffffu : ((1u << G) - 1u);
+    const uint32_t okGroup = static_cast<uint32_t>(okAll >> shift) & groupBits;
+    const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : G;   // lowest try that got through
+    // a dead pixel whose try 0 failed: 26 identical failures follow -- ITS (STRICT) state with weight 0 and 27 x its TIR bump, as pass
+    // A of the long lists hands it out (the other lanes' speculative tries of this ray count for nothing)
+    const bool deadEnd = round == 0u && deadPixel && (okGroup & 1u) == 0u && !done;
+    if (deadEnd) {
+        if (valid && j == 0u) {
+            tir += (kOutTries + 1u) * tirTry;
+            wOut = 0.0f;
+            if (T.exposureOn) wOut *= T.exposureMul;                      // zoic.cpp:1981-1987
+            flagsOut = 1u | (kOutTries << 1) | ((rs.flags & 1u) << 6);
+            emit = true;
+            ++vign;
+        }
+    } else {
+        if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
+        const bool last = k == kOutTries;                                  // try 26 failed as well: weight 0, ITS partial state
+        if (valid && (j == winner || (winner == G && last))) {
+            const bool okRay = j == winner && !last;
+            wOut = okRay ? 1.0f : 0.0f;
+            if (T.exposureOn) wOut *= T.exposureMul;                       // zoic.cpp:1981-1987
+            flagsOut = (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6);
+            emit = true;
+            succ += okRay ? 1u : 0u; vign += okRay ? 0u : 1u;
+        }
+    }
+    oOut = V3{o.x * -1.0f, o.y * -1.0f, o.z * -1.0f}; dOut = V3{d.x * -1.0f, d.y * -1.0f, d.z * -1.0f};   // zoic.cpp:1960-1961
+    return done || deadEnd || winner != G || G * (round + 1u) > kOutTries;
 }
 
-// Short lists: G = 16 tries of a ray side by side (round 3's listed_short; the rule per try is the one above).  The tries of a
-// ray are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1); the first success in try order wins and
-// TIR bumps count for the tries before it only (try 26 hands out its state with weight 0 whether it got through or not,
-// zoic.cpp:1927 / 1951).
+// Short lists: kShortGroup tries of a ray side by side, 64 / kShortGroup rays per wave.
 __device__ __forceinline__ uint32_t short_group_for(uint32_t n) { return n <= 16384u ? 16u : (n <= 32768u ? 8u : 4u); }
+// a dead pixel (outside the image circle) whose try 0 fails: its 26 retries are that try again (kolb_pool_body.hpp) -- unless the sample
+// is one of the few the sampler maps to a non-finite lens point
+__device__ __forceinline__ bool listed_dead_pixel(const KolbTable &T, const BokehTables &B, const float *bokehLds, const RaySetup &rs, const float4 &s)
+{
+    bool deadPixel = rs.dead;
+    if (deadPixel) {
+        const bool plainSample = (s.z >= 0.0f) & (s.z < 1.0f) & (s.w >= 0.0f) & (s.w < 1.0f) & !((s.z == 0.5f) & (s.w == 0.5f));
+        if (!plainSample) { const V2 l0 = lens_sample<true>(T, B, bokehLds, s.z, s.w); deadPixel = (fabsf(l0.x) <= 3.0e38f) && (fabsf(l0.y) <= 3.0e38f); }
+    }
+    return deadPixel;
+}
 template <int NS, uint32_t kShortGroup>
 __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
                                                     const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out)
@@ -183,104 +249,16 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
         const uint32_t idx = list[have ? li : n - 1u];
         const float4 s = samples[idx];
         const RaySetup rs = setup_ray<true>(T, lutLds, s.x, s.y);
-        const V3 o0{rs.o0x, rs.o0y, T.originShift};
         Rng rng;
         if (states) { const uint4 q = states[idx]; rng = Rng{q.x, q.y, q.z, q.w}; }
         else rng = rng_for_ray(T.seed, rayBase + idx);
         for (uint32_t a = 1; a < j; ++a) { (void)xor128(rng); (void)xor128(rng); }   // lane j >= 1 starts at draw 2 (j - 1)
         bool done = !have;
-        // a dead pixel (outside the image circle) whose try 0 fails: its 26 retries are that try again (kolb_pool_body.hpp)
-        bool deadPixel = rs.dead;
-        if (deadPixel) {
-            const bool plainSample = (s.z >= 0.0f) & (s.z < 1.0f) & (s.w >= 0.0f) & (s.w < 1.0f) & !((s.z == 0.5f) & (s.w == 0.5f));
-            if (!plainSample) { const V2 l0 = lens_sample<true>(T, B, bokehLds, s.z, s.w); deadPixel = (fabsf(l0.x) <= 3.0e38f) && (fabsf(l0.y) <= 3.0e38f); }
-        }
+        const bool deadPixel = listed_dead_pixel(T, B, bokehLds, rs, s);
         for (uint32_t round = 0; round * kShortGroup <= static_cast<uint32_t>(kMaxTries) + 1u; ++round) {
-            const uint32_t k = kShortGroup * round + j;                      // this lane's try: 0 = the sample's own lens point, k = tries
-            const bool valid = !done && k <= static_cast<uint32_t>(kMaxTries) + 1u;
-            V3 o = o0, d{0.0f, 0.0f, 1.0f};
-            uint32_t tirTry = 0;
-            bool ok = false, unsure = false;
-            float u = 0.0f, v = 0.0f;
-            // every lane's direction first; then ONE FAST-guarded trace for the tries k >= 1 of the whole wave -- the predicated trace of
-            // the long-list path, so that a ray's bits do not depend on the path (one arithmetic, written with explicit FMAs: fast_optics.hpp) --
-            // and the reference's arithmetic for try 0 and for the tries that were too close to call
-            if (valid) {
-                if (k == 0u) {
-                    V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
-                    if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
-                    else {                                                    // zoic.cpp:1913-1924: x-only translation
-                        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
-                        lens.x += rs.translation;
-                        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
-                        d = V3{rx - o.x, ry - o.y, T.dirZ};
-                    }
-                } else {
-                    u = rng_unit(xor128(rng));                                // zoic.cpp:1930
-                    v = rng_unit(xor128(rng));
-                    d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-                }
-            }
-            const bool fastTry = valid && k != 0u;
-            if constexpr (NS > 0) {
-                const unsigned long long fastMask = __ballot(fastTry);
-                if (fastMask != 0ull) {
-                    // the search's interface-0 test first, exactly as a B pass takes it (a try that dies there leaves (o, d) untouched)
-                    bool near0 = false;
-                    const bool pass0 = interface0_clear_fast<true>(load_surface<false>(kernarg_fast_surfaces(), 0), o, d, near0);
-                    const bool cand = fastTry && pass0 && !near0;
-                    unsure = fastTry && near0;
-                    unsigned long long tirMask, unsureMask;
-                    V3 ot = o, dt = d;
-                    const unsigned long long alive = trace_lens_fast_pred<NS, true>(kernarg_fast_surfaces(), ot, dt, __ballot(cand), tirMask, unsureMask);
-                    if (cand) {
-                        ok = mask_bit(alive, lane);
-                        tirTry = mask_bit(tirMask, lane) ? 1u : 0u;
-                        unsure |= mask_bit(unsureMask, lane);
-                        if (ok) { o = ot; d = dt; }
-                        else if (!unsure && k == static_cast<uint32_t>(kMaxTries) + 1u) {   // only try 26's partial state is ever handed out
-                            uint32_t ignored = 0;
-                            (void)trace_lens_fast_rolled(T, o, d, ignored);
-                        }
-                    }
-                }
-            } else if (fastTry) ok = trace_lens_fast_rolled(T, o, d, tirTry, &unsure);
-            if (valid && (k == 0u || unsure)) {   // the reference's arithmetic: try 0, and a try too close to call (same draws)
-                o = o0; tirTry = 0;
-                if (k != 0u) d = listed_retry_direction_strict(T, B, bokehLds, u, v, rs.o0x, rs.o0y, rs.maxScale, rs.translation, rs.sn, rs.cs);
-                ok = listed_strict_try(T, o, d, tirTry);
-            }
-            // the next try of this lane, k + G, starts at draw 2 (k + G - 1): G - 1 pairs past where this try ended (2 k; try 0 drew nothing)
-            for (uint32_t a = 0; a + 1u < kShortGroup; ++a) { (void)xor128(rng); (void)xor128(rng); }
-            // the group's decision, in try order
-            const unsigned long long okAll = __ballot(valid && ok);
-            const uint32_t okGroup = static_cast<uint32_t>(okAll >> (kShortGroup * g)) & ((1u << kShortGroup) - 1u);
-            const uint32_t winner = okGroup ? static_cast<uint32_t>(__builtin_ctz(okGroup)) : kShortGroup;   // lowest try that got through
-            // a dead pixel whose try 0 failed: 26 identical failures follow -- ITS (STRICT) state with weight 0 and 27 x its TIR bump, as pass
-            // A of the long lists hands it out (the other lanes' speculative tries of this ray count for nothing)
-            const bool deadEnd = round == 0u && deadPixel && (okGroup & 1u) == 0u && !done;
-            const uint32_t kOutTries = static_cast<uint32_t>(kMaxTries) + 1u;
-            if (deadEnd) {
-                if (valid && j == 0u) {
-                    tir += (kOutTries + 1u) * tirTry;
-                    float w = 0.0f;
-                    if (T.exposureOn) w *= T.exposureMul;                      // zoic.cpp:1981-1987
-                    store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, 1u | (kOutTries << 1) | ((rs.flags & 1u) << 6));
-                    ++vign;
-                }
-            } else {
-                if (valid && j < winner) tir += tirTry;                            // only the tries the reference actually ran
-                const bool last = k == kOutTries;                                  // try 26 failed as well: weight 0, ITS partial state
-                if (valid && (j == winner || (winner == kShortGroup && last))) {
-                    const bool okRay = j == winner && !last;
-                    float w = okRay ? 1.0f : 0.0f;
-                    if (T.exposureOn) w *= T.exposureMul;                          // zoic.cpp:1981-1987
-                    store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
-                                     (k > 0u ? 1u : 0u) | (k << 1) | ((rs.flags & 1u) << 6));
-                    if (okRay) ++succ; else ++vign;
-                }
-            }
-            done = done || deadEnd || winner != kShortGroup || kShortGroup * (round + 1u) > kOutTries;
+            bool emit; V3 o, d; float w; uint32_t flags;
+            done = listed_group_round<NS>(T, B, bokehLds, s, rs, deadPixel, rng, kShortGroup, j, kShortGroup * g, round, done, emit, o, d, w, flags, succ, vign, tir);
+            if (emit) store_ray_record(out, idx, o.x, o.y, o.z, d.x, d.y, d.z, w, flags);
             if (__ballot(!done) == 0ull) break;
         }
     }

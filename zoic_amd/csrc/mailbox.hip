@@ -45,7 +45,7 @@
 // where the batch path runs thin_refill.hip's fast arithmetic, a per-sample ray and a batch ray of the same sample can differ in
 // low-order bits (never in a decision: the fast vignetting test is decision-safe); a TILE takes the batch path's arithmetic
 // (thin_vignet_try<true>) and equals it.  include/zoic_amd.h states this at zoic_camera_create_ray.
-#include "kolb_listed_body.hpp"   // listed_one_ray; kolb_pool_body.hpp: setup_ray, retry_direction (+ kolb_device.hpp: lens_sample, the traces, zoicDynLds)
+#include "kolb_listed_body.hpp"   // listed_group_round; kolb_pool_body.hpp: setup_ray, retry_direction (+ kolb_device.hpp: lens_sample, the traces, zoicDynLds)
 #include "mailbox.hpp"
 #include "thin_device.hpp"
 
@@ -100,8 +100,8 @@ __device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have
 // first (most rejected tries die there), then the trace.  TIR bumps count for the tries before the winner only; try 26 hands out
 // its (partial) state with weight 0 (zoic.cpp:1927 / 1951); dead pixels (outside the image circle all 27 tries are one) and
 // retry-dead rays (dead_ray_end) end at try 0's failure, as in the batch kernels; GUARD (decision-safe FAST): a try with a decision
-// inside a guard band, at or before the winner, sends the ray to the listed kernel's rule (listed_one_ray), evaluated by one lane
-// once the rounds are over.  Every try is evaluated by the same device functions as everywhere else in the library: same bits as
+// inside a guard band, at or before the winner, sends the ray to the listed kernel's rule (listed_group_round: its tries side by
+// side as well) once the rounds are over.  Every try is evaluated by the same device functions as everywhere else in the library: same bits as
 // the batch kernels and as the reference's loop order (tests/test_tile_gpu.py, tests/test_boundary_gpu.py).
 constexpr uint32_t kTileStageWords = 512;   // LDS stage per wave (THINLENS: 64 x 7 input dwords, then 64 x 8 record dwords)
 constexpr uint32_t kKolbBatch = kTileRaysRaytraced;   // rays per wave pass (mailbox.hpp)
@@ -122,7 +122,7 @@ static_assert(sizeof(RayState) == 80 && kStageState + kKolbBatch * 20u <= kStage
 // Evaluates the rays 0 ... cnt-1 whose samples sit in `samples` (one per ray, lane r < cnt holds ray r's) and leaves their records
 // (ox oy oz dx dy dz weight flags, already negated, zoic.cpp:1960-1961) in stage[8 r ...].  rngOf(r): ray r's retry stream at its first
 // draw.  succ / vign / tir: the calling lane's counters.
-template <bool STRICT, bool GUARD, class RngOf>
+template <bool STRICT, bool GUARD, int NS, class RngOf>
 __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds, float *stage,
                                                float4 sample, uint32_t cnt, uint32_t lane, RngOf rngOf, uint32_t &succ, uint32_t &vign, uint32_t &tir)
 {
@@ -176,7 +176,7 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
         const bool deadPixel = (q.flags & 0x500u) == 0x500u, retryDead = (q.flags & kRetryDeadBit) != 0u;
         const V3 o0{q.o0x, q.o0y, T.originShift};
         V3 o = o0, d{0.0f, 0.0f, 1.0f};
-        bool ok = false, near = false;
+        bool ok = false, near = false, pass0 = false;
         uint32_t tirTry = 0;
         if (valid) {
             if (k == 0u) {                              // the sample's own lens point, zoic.cpp:1870-1924
@@ -200,15 +200,31 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
                 d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, u, v), q.o0x, q.o0y, q.maxScale, q.translation, q.sn, q.cs);
             }
             // interface 0 first (most rejected tries die there: a clip leaves (o, d) untouched and bumps nothing), then the trace
-            bool pass0;
             if constexpr (STRICT) {
                 bool inRange;
                 pass0 = interface0_clear_strict_lean(T, o0, d, inRange);
                 if (__builtin_expect(!inRange, 0)) pass0 = interface0_clear_strict(T, o0, d);   // never seen: guarded roots
             } else pass0 = interface0_clear_fast<GUARD>(T.fsurf[0], o0, d, near);
-            if (pass0 && !near) {
-                if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
-                else ok = trace_lens_fast_rolled(T, o, d, tirTry, GUARD ? &near : nullptr);
+            if constexpr (STRICT || NS == 0) {
+                if (pass0 && !near) {
+                    if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
+                    else ok = trace_lens_fast_rolled(T, o, d, tirTry, GUARD ? &near : nullptr);
+                }
+            }
+        }
+        if constexpr (!STRICT && NS > 0) {
+            // FAST with a known interface count: ONE predicated, unrolled trace for all the wave's tries (27 instructions per interface and
+            // the table words requested an interface ahead, against ~45 and three scalar-cache round trips per interface in the branchy
+            // loop: a lone wave waits for every one of them).  KEEP: a try that fails is left with the branchy trace's partial state --
+            // what try 26 hands out (zoic.cpp:1951-1961) -- so no second trace is ever needed.  Same FastHit / fast_refract: same bits.
+            const bool cand = valid && pass0 && !near;
+            const unsigned long long candMask = __ballot(cand);
+            if (candMask != 0ull) {
+                unsigned long long tirMask, unsureMask;
+                const unsigned long long alive = trace_lens_fast_pred<NS, GUARD, true>(kernarg_fast_surfaces(), o, d, candMask, tirMask, unsureMask);
+                ok = cand && mask_bit(alive, lane);
+                tirTry = (cand && mask_bit(tirMask, lane)) ? 1u : 0u;
+                if constexpr (GUARD) near = near || (cand && mask_bit(unsureMask, lane));
             }
         }
         // ---- the ray's decision, in try order, by the L lanes of its block ---------------------------------------------------------------
@@ -238,7 +254,7 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
             records[2u * ray] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);   // zoic.cpp:1960-1961
             records[2u * ray + 1u] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | ((q.flags & 1u) << 6)));
             tir += tally;
-            if (vignetted) ++vign; else ++succ;
+            vign += vignetted ? 1u : 0u; succ += vignetted ? 0u : 1u;   // (written as selects: `if ... ++a; else ++b;` became an indexed counter in scratch)
         }
         if (mine && outcome == 0u && t == 0u) { state[ray].nextTry = q.nextTry + L; state[ray].tirTally = tally; }
         if (mine && outcome == 3u && t == 0u) state[ray].tirTally = tally;
@@ -254,30 +270,54 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
         open = stillOpen;
         wave_lds_fence();
     }
-    // ---- the rays the rounds could not finish: one lane each ---------------------------------------------------------------------------------
-    uint32_t later = listedMask | deadEndMask;
-    if (later != 0u) {
-        uint32_t m = later;
+    // ---- retry-dead rays whose try 0 failed: the state of the last draw, one lane each ------------------------------------------------------
+    if (deadEndMask != 0u) {
+        uint32_t m = deadEndMask;
         for (uint32_t i = 0; i < lane && m != 0u; ++i) m &= m - 1u;
-        if (lane < static_cast<uint32_t>(__builtin_popcount(later)) && m != 0u) {
+        if (lane < static_cast<uint32_t>(__builtin_popcount(deadEndMask)) && m != 0u) {
             const uint32_t ray = static_cast<uint32_t>(__builtin_ctz(m));
             const RayState q = state[ray];
-            V3 o, d; float w; uint32_t tries, lutMiss = q.flags & 1u, tirRay; bool vignetted;
-            if ((deadEndMask >> ray) & 1u) {   // a retry-dead ray whose try 0 failed: the state of the last draw
-                RaySetup rs;
-                rs.o0x = q.o0x; rs.o0y = q.o0y; rs.maxScale = q.maxScale; rs.translation = q.translation; rs.sn = q.sn; rs.cs = q.cs; rs.flags = q.flags & (1u | kRetryDeadBit);
-                rs.dead = false; rs.lutEdge = false;
-                const DeadRayEnd e = dead_ray_end<STRICT>(T, B, bokehLds, rs, Rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]});
-                o = e.o; d = e.d; w = e.w; tries = e.tries; vignetted = !e.nanDraw; tirRay = q.tirTally;
-            } else {                           // a decision too close to call: the ray as the batch path's listed kernel evaluates it
-                const ListedRay l = listed_one_ray(T, B, lutLds, bokehLds, make_float4(q.sx, q.sy, q.lensx, q.lensy), Rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]});
-                o = l.o; d = l.d; w = l.w; tries = l.tries; lutMiss = l.lutMiss; tirRay = l.tir;
-                vignetted = tries > static_cast<uint32_t>(kMaxTries);
+            RaySetup rs;
+            rs.o0x = q.o0x; rs.o0y = q.o0y; rs.maxScale = q.maxScale; rs.translation = q.translation; rs.sn = q.sn; rs.cs = q.cs; rs.flags = q.flags & (1u | kRetryDeadBit);
+            rs.dead = false; rs.lutEdge = false;
+            const DeadRayEnd e = dead_ray_end<STRICT>(T, B, bokehLds, rs, Rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]});
+            records[2u * ray] = make_float4(e.o.x * -1.0f, e.o.y * -1.0f, e.o.z * -1.0f, e.d.x * -1.0f);
+            records[2u * ray + 1u] = make_float4(e.d.y * -1.0f, e.d.z * -1.0f, e.w, __builtin_bit_cast(float, (e.tries > 0 ? 1u : 0u) | (e.tries << 1) | ((q.flags & 1u) << 6)));
+            tir += q.tirTally;
+            vign += e.nanDraw ? 0u : 1u; succ += e.nanDraw ? 1u : 0u;
+        }
+    }
+    // ---- rays with a decision too close to call: the listed kernel's rule (kolb_listed_body.hpp), the tries of a ray side by side ----------
+    // in the G lanes the wave can spare per listed ray (one listed ray: all 27 tries at once).  What a batch with such a ray waits for is
+    // then ONE chain -- the reference's set-up, then try 0 in the reference's arithmetic up to the stop next to the FAST-guarded retries --
+    // where one lane used to run set-up, try 0 and every retry one after the other (+12 us on its batch, measured: the batches
+    // a 4096-sample tile waited for).  Same device function as the listed kernel's short lists: same bits whatever evaluates the ray.
+    if constexpr (GUARD) {
+        if (listedMask != 0u) {
+            const uint32_t nListed = static_cast<uint32_t>(__builtin_popcount(listedMask));
+            uint32_t G = 32u;
+            while (G * nListed > 64u) G >>= 1;
+            const uint32_t pos = lane / G, j = lane & (G - 1u), shift = lane & ~(G - 1u);
+            uint32_t m = listedMask;
+            for (uint32_t i = 0; i < pos && m != 0u; ++i) m &= m - 1u;
+            const bool have = pos < nListed && m != 0u;
+            const uint32_t ray = have ? static_cast<uint32_t>(__builtin_ctz(m)) : static_cast<uint32_t>(__builtin_ctz(listedMask));
+            const RayState q = state[ray];
+            const float4 s4 = make_float4(q.sx, q.sy, q.lensx, q.lensy);
+            const RaySetup rs = setup_ray<true>(T, lutLds, s4.x, s4.y);
+            Rng rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]};
+            for (uint32_t a = 1; a < j; ++a) { (void)xor128(rng); (void)xor128(rng); }   // lane j >= 1 starts at draw 2 (j - 1)
+            const bool deadPixel = listed_dead_pixel(T, B, bokehLds, rs, s4);
+            bool done = !have;
+            for (uint32_t round = 0; round * G <= kOut; ++round) {
+                bool emit; V3 o, d; float w; uint32_t flags;
+                done = listed_group_round<NS>(T, B, bokehLds, s4, rs, deadPixel, rng, G, j, shift, round, done, emit, o, d, w, flags, succ, vign, tir);
+                if (emit) {
+                    records[2u * ray] = make_float4(o.x, o.y, o.z, d.x);
+                    records[2u * ray + 1u] = make_float4(d.y, d.z, w, __builtin_bit_cast(float, flags));
+                }
+                if (__ballot(!done) == 0ull) break;
             }
-            records[2u * ray] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);
-            records[2u * ray + 1u] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | (lutMiss << 6)));
-            tir += tirRay;
-            if (vignetted) ++vign; else ++succ;
         }
     }
     wave_lds_fence();
@@ -323,7 +363,8 @@ __device__ __forceinline__ unsigned long long first_lane64(unsigned long long v)
 // have left, [2..3] wall-clock time of the last call any wave answered, [4..5] the work mask.
 // One kernel per (lens model, precision mode): a resident wave is alone on its SIMD and waits for its instruction fetches like for
 // everything else -- with all six combinations in one kernel (138 KB of code against a 64 KB instruction cache) every pass missed.
-template <int MODEL, int MODE>
+// NS: the lens's interface count where the FAST modes have an unrolled trace for it (7 ... 12, as the batch kernels), 0 otherwise.
+template <int MODEL, int MODE, int NS>
 __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, const ThinTable Th, const BokehTables B, char *mapped,
                                                              MailDeviceState *st, DeviceCounters *counters, uint32_t ldsWords, uint32_t totalWaves)
 {
@@ -584,7 +625,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                     r = thin_ray_strict(Th, B, bokehLds, s, q, [] {});
                 }
                 o = r.origin; d = r.dir; w = r.w; tries = r.tries;
-                if (Th.useDof) { if (tries > static_cast<uint32_t>(kMaxTries)) ++vign; else ++succ; }
+                if (Th.useDof) { const bool out = tries > static_cast<uint32_t>(kMaxTries); vign += out ? 1u : 0u; succ += out ? 0u : 1u; }
                 float4 *rec = reinterpret_cast<float4 *>(stage) + 2u * lane;
                 rec[0] = make_float4(o.x, o.y, o.z, d.x);
                 rec[1] = make_float4(d.y, d.z, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1)));
@@ -594,7 +635,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             const bool tileWork = work == 2u;
             const uint32_t seed = T.seed;
             const auto rngOf = [&](uint32_t ray) { return tileWork ? rng_for_ray(seed, rayBase + ray) : rng; };
-            kolb_wave_rays<MODE == 0, MODE == 1>(T, B, lutLds, bokehLds, stage, s, cnt, lane, rngOf, succ, vign, tir);
+            kolb_wave_rays<MODE == 0, MODE == 1, NS>(T, B, lutLds, bokehLds, stage, s, cnt, lane, rngOf, succ, vign, tir);
         }
 
 #ifdef ZOIC_TILE_TIMING
@@ -685,14 +726,25 @@ int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTabl
     const uint32_t ldsWords = (image && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
     const uint32_t groups = kMailSlotGroups + workerGroups;
     const size_t lds = (kLutLdsWords + ldsWords + (kMailBlock / 64u) * kTileStageWords) * sizeof(float);
-#define ZOIC_LAUNCH_MAILBOX(MODEL_, MODE_)                                                                                       \
-    hipLaunchKernelGGL((mailbox_kernel<MODEL_, MODE_>), dim3(groups), dim3(kMailBlock), lds, static_cast<hipStream_t>(stream), kolb, thin, bokeh, \
+#define ZOIC_LAUNCH_MAILBOX(MODEL_, MODE_, NS_)                                                                                  \
+    hipLaunchKernelGGL((mailbox_kernel<MODEL_, MODE_, NS_>), dim3(groups), dim3(kMailBlock), lds, static_cast<hipStream_t>(stream), kolb, thin, bokeh, \
                        static_cast<char *>(d_mapped), d_state, d_counters, ldsWords, groups * (kMailBlock / 64u))
+#define ZOIC_LAUNCH_MAILBOX_BY_COUNT(MODE_)                                                                                      \
+    switch (kolb.lensCount) {  /* unrolled traces for the interface counts of real prescriptions (kolb_pool_body.hpp) */        \
+    case 7: ZOIC_LAUNCH_MAILBOX(1, MODE_, 7); break;                                                                             \
+    case 8: ZOIC_LAUNCH_MAILBOX(1, MODE_, 8); break;                                                                             \
+    case 9: ZOIC_LAUNCH_MAILBOX(1, MODE_, 9); break;                                                                             \
+    case 10: ZOIC_LAUNCH_MAILBOX(1, MODE_, 10); break;                                                                           \
+    case 11: ZOIC_LAUNCH_MAILBOX(1, MODE_, 11); break;                                                                           \
+    case 12: ZOIC_LAUNCH_MAILBOX(1, MODE_, 12); break;                                                                           \
+    default: ZOIC_LAUNCH_MAILBOX(1, MODE_, 0); break;                                                                            \
+    }
     if (model == 0) {   // (THINLENS: MODE only tells the vignetting loop's arithmetic apart)
-        if (mode == 0) ZOIC_LAUNCH_MAILBOX(0, 0); else ZOIC_LAUNCH_MAILBOX(0, 1);
-    } else if (mode == 0) ZOIC_LAUNCH_MAILBOX(1, 0);
-    else if (mode == 1) ZOIC_LAUNCH_MAILBOX(1, 1);
-    else ZOIC_LAUNCH_MAILBOX(1, 2);
+        if (mode == 0) ZOIC_LAUNCH_MAILBOX(0, 0, 0); else ZOIC_LAUNCH_MAILBOX(0, 1, 0);
+    } else if (mode == 0) ZOIC_LAUNCH_MAILBOX(1, 0, 0);
+    else if (mode == 1) { ZOIC_LAUNCH_MAILBOX_BY_COUNT(1) }
+    else { ZOIC_LAUNCH_MAILBOX_BY_COUNT(2) }
+#undef ZOIC_LAUNCH_MAILBOX_BY_COUNT
 #undef ZOIC_LAUNCH_MAILBOX
     return static_cast<int>(hipGetLastError());
 }
