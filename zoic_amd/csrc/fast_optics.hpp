@@ -270,12 +270,7 @@ __device__ __forceinline__ bool trace_lens_fast_rolled_from(FastSurfaceTable sur
 // finish dead get their reference partial state from trace_lens_fast_rolled).  tirMask: lanes that were totally reflected.
 // GUARD (decision-safe mode): unsureMask collects the lanes still alive at a guarded interface whose clip decision lies inside
 // the guard band.
-// KEEP (the resident tile workers, mailbox.hip): a lane that dies keeps the PARTIAL state the branchy trace leaves on the same exit -- clipped:
-// (o, u) as they arrived at that interface; totally reflected: o advanced to the hit, u as it arrived; d = the raw direction if the
-// ray never got through a refraction, the last refracted unit direction otherwise -- so that a ray that finishes failed needs no second,
-// branchy trace (a lone wave waits for its chain of dependent instructions: six v_cndmask per interface off that chain cost it nothing,
-// a second trace costs a whole round).  The arithmetic per interface is the same FastHit / fast_refract: same bits.
-template <int NS, bool GUARD = false, bool KEEP = false>
+template <int NS, bool GUARD = false>
 __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTable surf, V3 &o, V3 &d, unsigned long long alive0,
                                                                    unsigned long long &tirMask, unsigned long long &unsureMask)
 {
@@ -285,7 +280,6 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
     float oAxis2 = fast_axis2(o);
     unsigned long long alive = alive0, tirSeen = 0ull, unsure = 0ull;   // alive0: lanes without a candidate ride along dead
     unsigned long long nanRays = 0ull;                                  // candidates that arrived as NaN: they "pass" everything
-    unsigned long long refracted = 0ull;                                // KEEP: lanes that got through interface 0's refraction
     // The table words of interface i + 1 are requested BEFORE interface i is evaluated (scalar loads return out of order, so
     // the only wait there is is lgkmcnt(0): `surface_arrived` takes it at the end of interface i, a whole interface -- ~30 VALU --
     // after the request; the sched_barrier keeps the scheduler from sinking the request towards its use).  Loading at the use
@@ -308,36 +302,83 @@ __device__ __forceinline__ unsigned long long trace_lens_fast_pred(FastSurfaceTa
             clipped = ~__ballot(h.h2 <= S.housingLo);
             unsure |= alive & clipped & __ballot(h.h2 <= S.housingHi);
         } else clipped = ~__ballot(h.h2 <= S.housing2);   // the stop's housing2 includes the user aperture
-        if constexpr (KEEP) {
-            // a NaN ray is clipped nowhere (the branchy trace: !(h2 <= housing2) && !is_nan_ray): it stays alive and its state goes NaN
-            clipped &= ~nanRays;
-            alive &= ~clipped;
-            const bool through = __builtin_amdgcn_inverse_ballot_w64(alive);
-            o = V3{through ? h.hit.x : o.x, through ? h.hit.y : o.y, through ? h.hit.z : o.z};
-            oAxis2 = h.h2;
-            V3 un = u;
-            const unsigned long long tirHere = __ballot(fast_refract(S, h, un) < 0.0f);
-            tirSeen |= alive & tirHere;
-            alive &= ~tirHere;
-            const bool bent = __builtin_amdgcn_inverse_ballot_w64(alive);
-            u = V3{bent ? un.x : u.x, bent ? un.y : u.y, bent ? un.z : u.z};
-            if (i == 0) refracted = alive;
-        } else {
         o = h.hit;
         oAxis2 = h.h2;
         const unsigned long long tirHere = __ballot(fast_refract(S, h, u) < 0.0f);
         alive &= ~clipped;
         tirSeen |= alive & tirHere;                      // counted only by rays that reached the refraction
         alive &= ~tirHere;
-        }
         if constexpr (ZOIC_TRACE_PREFETCH != 0) { if (i + 1 < NS) surface_arrived(Sn); S = Sn; }   // ... and is waited for here, in the same block
         else if (i + 1 < NS) S = load_surface<GUARD && (ZOIC_GUARD_PIN != 0)>(surf, i + 1);
     }
     tirMask = tirSeen;
     unsureMask = unsure;
-    if constexpr (KEEP) { if (__builtin_amdgcn_inverse_ballot_w64(refracted)) d = u; return alive; }
     d = u;
     return alive | (alive0 & nanRays);
+}
+
+// The same trace for R rays PER LANE, keeping a failed ray's partial state (the resident tile workers, mailbox.hip).
+//   * R rays per lane: a resident wave is alone on its SIMD and retires a dependent instruction every ~10 cycles, so a second,
+//     independent ray in the same lanes rides in the first one's latency (two tries of a ray evaluated in the time of ~1.2);
+//   * KEEP: a lane that dies keeps the PARTIAL state the branchy trace leaves on the same exit -- clipped: (o, u) as they arrived at that
+//     interface; totally reflected: o advanced to the hit, u as it arrived; d = the raw direction if the ray never got through a
+//     refraction, the last refracted unit direction otherwise -- so that a ray that finishes failed (try 26, zoic.cpp:1951-1961) needs
+//     no second, branchy trace: six v_cndmask per interface off the chain against a whole round on it.
+// The arithmetic per interface is the same FastHit / fast_refract as everywhere: same bits.  alive[r]: in = the lanes whose ray r is a
+// candidate, out = the lanes whose ray r got through (a ray that arrived NaN is clipped nowhere, as in the branchy trace: it stays
+// alive and its state goes NaN).
+template <int NS, bool GUARD, int R>
+__device__ __forceinline__ void trace_lens_fast_pred_keep(FastSurfaceTable surf, V3 (&o)[R], V3 (&d)[R], unsigned long long (&alive)[R],
+                                                          unsigned long long (&tirMask)[R], unsigned long long (&unsureMask)[R])
+{
+    static_assert(NS > 0 && R >= 1, "predicated trace needs a compile-time interface count");
+    V3 u[R];
+    float oAxis2[R];
+    unsigned long long nanRays[R], refracted[R];
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float inv = frsq_fast(fast_norm2(d[r]));
+        u[r] = V3{d[r].x * inv, d[r].y * inv, d[r].z * inv};
+        oAxis2[r] = fast_axis2(o[r]);
+        tirMask[r] = 0ull; unsureMask[r] = 0ull; nanRays[r] = 0ull; refracted[r] = 0ull;
+        any |= alive[r];
+    }
+    FastSurface S = load_surface<true>(surf, 0);
+    surface_arrived(S);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (i >= 2 && (i & 1) == 0 && any == 0ull) break;   // wave-uniform early out, every 2nd interface
+        FastSurface Sn = S;
+        if (i + 1 < NS) { Sn = load_surface<true>(surf, i + 1); __builtin_amdgcn_sched_barrier(0); }   // the next interface's words are requested HERE
+        any = 0ull;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const FastHit h = fast_hit(S, o[r], oAxis2[r], u[r]);
+            if (i == 0) nanRays[r] = __ballot(is_nan_ray(h));
+            unsigned long long clipped;
+            if constexpr (GUARD) {
+                clipped = ~__ballot(h.h2 <= S.housingLo);
+                unsureMask[r] |= alive[r] & clipped & __ballot(h.h2 <= S.housingHi);
+            } else clipped = ~__ballot(h.h2 <= S.housing2);
+            alive[r] &= ~(clipped & ~nanRays[r]);
+            const bool through = __builtin_amdgcn_inverse_ballot_w64(alive[r]);
+            o[r] = V3{through ? h.hit.x : o[r].x, through ? h.hit.y : o[r].y, through ? h.hit.z : o[r].z};
+            oAxis2[r] = h.h2;
+            V3 un = u[r];
+            const unsigned long long tirHere = __ballot(fast_refract(S, h, un) < 0.0f);
+            tirMask[r] |= alive[r] & tirHere;                // counted only by rays that reached the refraction
+            alive[r] &= ~tirHere;
+            const bool bent = __builtin_amdgcn_inverse_ballot_w64(alive[r]);
+            u[r] = V3{bent ? un.x : u[r].x, bent ? un.y : u[r].y, bent ? un.z : u[r].z};
+            if (i == 0) refracted[r] = alive[r];
+            any |= alive[r];
+        }
+        if (i + 1 < NS) surface_arrived(Sn);
+        S = Sn;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { if (__builtin_amdgcn_inverse_ballot_w64(refracted[r])) d[r] = u[r]; }
 }
 
 }  // namespace zoic

@@ -103,20 +103,21 @@ __device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have
 // inside a guard band, at or before the winner, sends the ray to the listed kernel's rule (listed_group_round: its tries side by
 // side as well) once the rounds are over.  Every try is evaluated by the same device functions as everywhere else in the library: same bits as
 // the batch kernels and as the reference's loop order (tests/test_tile_gpu.py, tests/test_boundary_gpu.py).
-constexpr uint32_t kTileStageWords = 512;   // LDS stage per wave (THINLENS: 64 x 7 input dwords, then 64 x 8 record dwords)
+constexpr uint32_t kTileStageWords = 576;   // LDS stage per wave (THINLENS: 64 x 7 input dwords, then 64 x 8 record dwords)
 constexpr uint32_t kKolbBatch = kTileRaysRaytraced;   // rays per wave pass (mailbox.hpp)
 // LDS stage of a wave (kTileStageWords dwords): [0, 128) the finished records, 8 dwords per ray (what the output stage reads);
-// [128, 448) the rays' state, 20 dwords each; [384, 496) the batch's input rows on arrival (dead before the state is written);
-// [448, 452) a round's outcome masks
-constexpr uint32_t kStageState = 128, kStageInput = 384, kStageMasks = 448;
-struct RayState {     // 20 dwords
+// [128, 512) the rays' state, 24 dwords each; [384, 496) the batch's input rows on arrival (dead before the state is written);
+// [512, 516) a round's outcome masks
+constexpr uint32_t kStageState = 128, kStageInput = 384, kStageMasks = 512;
+struct RayState {     // 24 dwords
     float sx, sy, lensx, lensy;                         // the sample
     uint32_t rng[4];                                    // the ray's retry stream at its first draw
     float o0x, o0y, maxScale, translation, sn, cs;      // RaySetup
     uint32_t flags;                                     // RaySetup::flags | dead pixel << 8 | lutEdge << 9 | try 0's sample finite << 10
     uint32_t nextTry, tirTally, pad[3];
+    uint32_t rngNext[4];                                // the stream at the draws of try max(nextTry, 1): a round's lanes step on from here
 };
-static_assert(sizeof(RayState) == 80 && kStageState + kKolbBatch * 20u <= kStageMasks && kStageMasks + 4u <= kTileStageWords, "stage layout");
+static_assert(sizeof(RayState) == 96 && kStageState + kKolbBatch * 24u <= kStageMasks && kStageMasks + 4u <= kTileStageWords, "stage layout");
 // (the state overlaps the input rows: they are in registers before the first state word is written)
 
 // Evaluates the rays 0 ... cnt-1 whose samples sit in `samples` (one per ray, lane r < cnt holds ray r's) and leaves their records
@@ -147,18 +148,26 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
             q.nextTry = 0u; q.tirTally = 0u;
             const Rng r0 = rngOf(lane);
             q.rng[0] = r0.x; q.rng[1] = r0.y; q.rng[2] = r0.z; q.rng[3] = r0.w;
+            q.rngNext[0] = r0.x; q.rngNext[1] = r0.y; q.rngNext[2] = r0.z; q.rngNext[3] = r0.w;
         }
         if constexpr (GUARD) listedMask = static_cast<uint32_t>(__ballot(lane < cnt && T.useLUT && rs.lutEdge));   // the exit-pupil LUT's only discontinuity: the table's end
     }
     wave_lds_fence();
     uint32_t open = (cnt >= 32u ? 0xffffffffu : ((1u << cnt) - 1u)) & ~listedMask;   // wave-uniform: rays with tries to run
+    // R = tries per LANE.  Measured with R = 2 where the unrolled FAST trace exists (lane t of a block: tries nextTry + t and nextTry + L + t,
+    // round 0 covering tries 0 ... 7) [MI355X, profiles/ab_r05/tile_latency_v8.txt, _v9.txt]: a 4096-sample tile 29.1 -> 28.5 us, but a
+    // 64-sample tile 17.3 -> 19.6 and the per-sample call 7.1 -> 8.6 us.  A lone wave is not waiting for its dependent instructions -- a wave64
+    // VALU instruction issues every 4 cycles whether or not it depends on the one before -- it is paying for every instruction it issues
+    // (and for every taken branch and scalar-load wait), so a second try in the same lane costs what it would cost in another round.  R = 1.
+    constexpr int R = 1;
     bool firstRound = true;
     while (open != 0u) {
-        // ---- this round's lanes: L per open ray (4 in round 0, up to 32 for the stragglers) -------------------------------------------
-        // (round 0 stays at four tries per ray however few rays there are: lane t of a block steps the ray's stream over t - 1 draw pairs
-        // first, and 25 of those in front of a single sample's first round cost its median call 1.2 us for tries 95 % of the rays never need)
+        // ---- this round's lanes: L per open ray (4 in round 0, up to 32 / R for the stragglers) ----------------------------------------
+        // (round 0 stays at four lanes per ray however few rays there are: a lane steps the ray's stream over the draws of the tries in
+        // front of its own first, and 25 of those in front of a single sample's first round cost its median call 1.2 us for tries 95 % of
+        // the rays never need)
         const uint32_t nOpen = static_cast<uint32_t>(__builtin_popcount(open));
-        uint32_t L = firstRound ? 4u : 32u;
+        uint32_t L = firstRound ? 4u : 32u / static_cast<uint32_t>(R);
         while (L * nOpen > 64u) L >>= 1;
         firstRound = false;
         const uint32_t pos = lane / L, t = lane & (L - 1u), blockBase = lane & ~(L - 1u);
@@ -171,92 +180,125 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
         }
         const bool mine = pos < nOpen;
         const RayState q = state[mine ? ray : static_cast<uint32_t>(__builtin_ctz(open))];
-        const uint32_t k = q.nextTry + t;               // this lane's try
-        const bool valid = mine && k <= kOut;
         const bool deadPixel = (q.flags & 0x500u) == 0x500u, retryDead = (q.flags & kRetryDeadBit) != 0u;
         const V3 o0{q.o0x, q.o0y, T.originShift};
-        V3 o = o0, d{0.0f, 0.0f, 1.0f};
-        bool ok = false, near = false, pass0 = false;
-        uint32_t tirTry = 0;
-        if (valid) {
-            if (k == 0u) {                              // the sample's own lens point, zoic.cpp:1870-1924
-                V2 lens = lens_sample<STRICT>(T, B, bokehLds, q.lensx, q.lensy);
-                if (deadPixel) {
-                    const bool plainSample = (q.lensx >= 0.0f) & (q.lensx < 1.0f) & (q.lensy >= 0.0f) & (q.lensy < 1.0f) & !((q.lensx == 0.5f) & (q.lensy == 0.5f));
-                    if (plainSample) lens = V2{0.0f, 0.0f};
-                }
-                if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};   // zoic.cpp:1873-1877
-                else {                                  // zoic.cpp:1913-1924: x-only translation on the first sample
-                    lens.x *= q.maxScale; lens.y *= q.maxScale;
-                    lens.x += q.translation;
-                    const float rx = lens.x * q.cs - lens.y * q.sn, ry = lens.x * q.sn + lens.y * q.cs;
-                    d = V3{rx - o0.x, ry - o0.y, T.dirZ};
-                }
-            } else {                                    // try k draws 2 (k - 1), 2 (k - 1) + 1 of the ray's stream, zoic.cpp:1930-1943
-                Rng rng{q.rng[0], q.rng[1], q.rng[2], q.rng[3]};
-                for (uint32_t a = 1; a < k; ++a) { (void)xor128(rng); (void)xor128(rng); }
-                const float u = rng_unit(xor128(rng));
-                const float v = rng_unit(xor128(rng));
-                d = retry_direction(T, lens_sample<STRICT>(T, B, bokehLds, u, v), q.o0x, q.o0y, q.maxScale, q.translation, q.sn, q.cs);
+        uint32_t k[R];                                  // this lane's tries
+        bool valid[R], ok[R], near[R], pass0[R];
+        uint32_t tirTry[R];
+        float su[R], sv[R];                             // the unit-square point each try's lens sample is made from
+        V3 o[R], d[R];
+        // (1) the draws, one try after the other: the ray's stream is sequential (try k >= 1 uses draws 2 (k - 1), 2 (k - 1) + 1, zoic.cpp:1930)
+        Rng rng{q.rngNext[0], q.rngNext[1], q.rngNext[2], q.rngNext[3]};
+        uint32_t at = q.nextTry > 1u ? q.nextTry : 1u;  // the try whose draws the stream stands at
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            k[r] = q.nextTry + static_cast<uint32_t>(r) * L + t;
+            valid[r] = mine && k[r] <= kOut;
+            su[r] = q.lensx; sv[r] = q.lensy;           // try 0: the sample's own point (zoic.cpp:1870)
+            if (valid[r] && k[r] != 0u) {
+                for (; at < k[r]; ++at) { (void)xor128(rng); (void)xor128(rng); }
+                su[r] = rng_unit(xor128(rng));
+                sv[r] = rng_unit(xor128(rng));
+                ++at;
+            }
+        }
+        // (2) lens sample, direction, interface 0 of every try: straight-line code, so that the R tries of a lane overlap (what is not
+        // valid is computed on whatever the registers hold and never looked at)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ok[r] = false; near[r] = false; tirTry[r] = 0u;
+            o[r] = o0;
+            const bool first = k[r] == 0u;
+            V2 lens = lens_sample<STRICT>(T, B, bokehLds, su[r], sv[r]);
+            if (!T.useLUT) d[r] = V3{(lens.x * T.rearAperture) - o0.x, (lens.y * T.rearAperture) - o0.y, T.dirZ};   // zoic.cpp:1873-1877 / 1882-1884
+            else {
+                // a dead pixel's try 0 shoots lens = (0, 0) whatever finite point the sampler returns (kolb_pool_body.hpp)
+                const bool plainSample = (q.lensx >= 0.0f) & (q.lensx < 1.0f) & (q.lensy >= 0.0f) & (q.lensy < 1.0f) & !((q.lensx == 0.5f) & (q.lensy == 0.5f));
+                if (first && deadPixel && plainSample) lens = V2{0.0f, 0.0f};
+                lens.x *= q.maxScale; lens.y *= q.maxScale;
+                lens.x += q.translation;
+                const float ly = lens.y + q.translation;
+                lens.y = first ? lens.y : ly;           // zoic.cpp:1914 translates the first sample in x only, 1933 the retries in both
+                const float rx = lens.x * q.cs - lens.y * q.sn, ry = lens.x * q.sn + lens.y * q.cs;
+                d[r] = V3{rx - o0.x, ry - o0.y, T.dirZ};
             }
             // interface 0 first (most rejected tries die there: a clip leaves (o, d) untouched and bumps nothing), then the trace
             if constexpr (STRICT) {
                 bool inRange;
-                pass0 = interface0_clear_strict_lean(T, o0, d, inRange);
-                if (__builtin_expect(!inRange, 0)) pass0 = interface0_clear_strict(T, o0, d);   // never seen: guarded roots
-            } else pass0 = interface0_clear_fast<GUARD>(T.fsurf[0], o0, d, near);
+                pass0[r] = interface0_clear_strict_lean(T, o0, d[r], inRange);
+                if (__builtin_expect(!inRange, 0)) pass0[r] = interface0_clear_strict(T, o0, d[r]);   // never seen: guarded roots
+            } else pass0[r] = interface0_clear_fast<GUARD>(T.fsurf[0], o0, d[r], near[r]);
+            pass0[r] = pass0[r] && valid[r]; near[r] = near[r] && valid[r];
+            if (!valid[r]) d[r] = V3{0.0f, 0.0f, 1.0f};
             if constexpr (STRICT || NS == 0) {
-                if (pass0 && !near) {
-                    if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
-                    else ok = trace_lens_fast_rolled(T, o, d, tirTry, GUARD ? &near : nullptr);
+                if (pass0[r] && !near[r]) {
+                    if constexpr (STRICT) ok[r] = trace_lens_strict(T, o[r], d[r], tirTry[r]);
+                    else ok[r] = trace_lens_fast_rolled(T, o[r], d[r], tirTry[r], GUARD ? &near[r] : nullptr);
                 }
             }
         }
         if constexpr (!STRICT && NS > 0) {
             // FAST with a known interface count: ONE predicated, unrolled trace for all the wave's tries (27 instructions per interface and
             // the table words requested an interface ahead, against ~45 and three scalar-cache round trips per interface in the branchy
-            // loop: a lone wave waits for every one of them).  KEEP: a try that fails is left with the branchy trace's partial state --
-            // what try 26 hands out (zoic.cpp:1951-1961) -- so no second trace is ever needed.  Same FastHit / fast_refract: same bits.
-            const bool cand = valid && pass0 && !near;
-            const unsigned long long candMask = __ballot(cand);
-            if (candMask != 0ull) {
-                unsigned long long tirMask, unsureMask;
-                const unsigned long long alive = trace_lens_fast_pred<NS, GUARD, true>(kernarg_fast_surfaces(), o, d, candMask, tirMask, unsureMask);
-                ok = cand && mask_bit(alive, lane);
-                tirTry = (cand && mask_bit(tirMask, lane)) ? 1u : 0u;
-                if constexpr (GUARD) near = near || (cand && mask_bit(unsureMask, lane));
+            // loop: a lone wave waits for every one of them).  A try that fails is left with the branchy trace's partial state -- what try
+            // 26 hands out (zoic.cpp:1951-1961) -- so no second trace is ever needed.  Same FastHit / fast_refract: same bits.
+            unsigned long long alive[R], tirMask[R], unsureMask[R];
+            unsigned long long anyCand = 0ull;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { alive[r] = __ballot(valid[r] && pass0[r] && !near[r]); anyCand |= alive[r]; }
+            if (anyCand != 0ull) {
+                unsigned long long cand[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) cand[r] = alive[r];
+                trace_lens_fast_pred_keep<NS, GUARD, R>(kernarg_fast_surfaces(), o, d, alive, tirMask, unsureMask);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    ok[r] = mask_bit(alive[r], lane);
+                    tirTry[r] = mask_bit(tirMask[r], lane) ? 1u : 0u;
+                    if constexpr (GUARD) near[r] = near[r] || mask_bit(unsureMask[r] & cand[r], lane);
+                }
             }
         }
-        // ---- the ray's decision, in try order, by the L lanes of its block ---------------------------------------------------------------
+        // ---- the ray's decision, in try order, by the L lanes of its block: try nextTry + i sits in lane i % L, slot i / L --------------------
         const unsigned long long blockMask = (L >= 32u ? 0xffffffffull : ((1ull << L) - 1ull));
-        const uint32_t okB = static_cast<uint32_t>((__ballot(valid && ok && !near) >> blockBase) & blockMask);
-        const uint32_t nearB = static_cast<uint32_t>((__ballot(valid && near) >> blockBase) & blockMask);
-        const uint32_t tirB = static_cast<uint32_t>((__ballot(valid && tirTry != 0u) >> blockBase) & blockMask);
-        const uint32_t winner = okB ? static_cast<uint32_t>(__builtin_ctz(okB)) : 32u;         // lowest try that got through
-        const uint32_t firstNear = nearB ? static_cast<uint32_t>(__builtin_ctz(nearB)) : 32u;
-        const bool firstFailed = q.nextTry == 0u && (okB & 1u) == 0u && (nearB & 1u) == 0u;       // try 0 failed, decided
-        // 0 open still, 1 finished by lane `holder`, 2 listed, 3 retry-dead end
+        uint32_t okW = 0, nearW = 0, tirW = 0;   // bit i: try nextTry + i (R x L <= 32)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            okW |= static_cast<uint32_t>((__ballot(valid[r] && ok[r] && !near[r]) >> blockBase) & blockMask) << (static_cast<uint32_t>(r) * L);
+            nearW |= static_cast<uint32_t>((__ballot(valid[r] && near[r]) >> blockBase) & blockMask) << (static_cast<uint32_t>(r) * L);
+            tirW |= static_cast<uint32_t>((__ballot(valid[r] && tirTry[r] != 0u) >> blockBase) & blockMask) << (static_cast<uint32_t>(r) * L);
+        }
+        const uint32_t winner = okW ? static_cast<uint32_t>(__builtin_ctz(okW)) : 32u;         // lowest try that got through
+        const uint32_t firstNear = nearW ? static_cast<uint32_t>(__builtin_ctz(nearW)) : 32u;
+        const bool firstFailed = q.nextTry == 0u && (okW & 1u) == 0u && (nearW & 1u) == 0u;       // try 0 failed, decided
+        // 0 open still, 1 finished by try nextTry + holder, 2 listed, 3 retry-dead end
         uint32_t outcome = 0, holder = 0, tirAdd = 0;
         if (GUARD && firstNear < 32u && firstNear < winner) outcome = 2;          // too close to call before anything got through
-        else if (firstFailed && deadPixel) { outcome = 1; holder = 0; tirAdd = (1u + kOut) * (tirB & 1u); }    // 26 more identical failures
-        else if (firstFailed && retryDead) { outcome = 3; tirAdd = tirB & 1u; }    // tries 1 ... 26 die at interface 0
-        else if (winner < 32u) { outcome = 1; holder = winner; tirAdd = static_cast<uint32_t>(__builtin_popcount(tirB & ((1u << winner) - 1u))); }   // only the tries the reference ran
+        else if (firstFailed && deadPixel) { outcome = 1; holder = 0; tirAdd = (1u + kOut) * (tirW & 1u); }    // 26 more identical failures
+        else if (firstFailed && retryDead) { outcome = 3; tirAdd = tirW & 1u; }    // tries 1 ... 26 die at interface 0
+        else if (winner < 32u) { outcome = 1; holder = winner; tirAdd = static_cast<uint32_t>(__builtin_popcount(tirW & ((1u << winner) - 1u))); }   // only the tries the reference ran
         else {
-            tirAdd = static_cast<uint32_t>(__builtin_popcount(tirB));
-            if (q.nextTry + L > kOut) { outcome = 1; holder = kOut - q.nextTry; }   // try 26 failed as well: ITS partial state, weight 0
+            tirAdd = static_cast<uint32_t>(__builtin_popcount(tirW));
+            if (q.nextTry + static_cast<uint32_t>(R) * L > kOut) { outcome = 1; holder = kOut - q.nextTry; }   // try 26 failed as well: ITS partial state, weight 0
         }
         const uint32_t tally = q.tirTally + tirAdd;
-        if (mine && outcome == 1u && t == holder) {
-            const uint32_t tries = (firstFailed && deadPixel) ? kOut : k;
+        if (mine && outcome == 1u && t == (holder & (L - 1u))) {
+            V3 oh = o[0], dh = d[0];
+            uint32_t kh = k[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) { if (holder / L == static_cast<uint32_t>(r)) { oh = o[r]; dh = d[r]; kh = k[r]; } }
+            const uint32_t tries = (firstFailed && deadPixel) ? kOut : kh;
             const bool vignetted = tries > static_cast<uint32_t>(kMaxTries);
             float w = vignetted ? 0.0f : 1.0f;                                  // zoic.cpp:1951-1957 (try 26 that got through as well)
             if (T.exposureOn) w *= T.exposureMul;                               // zoic.cpp:1981-1987
-            records[2u * ray] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);   // zoic.cpp:1960-1961
-            records[2u * ray + 1u] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | ((q.flags & 1u) << 6)));
+            records[2u * ray] = make_float4(oh.x * -1.0f, oh.y * -1.0f, oh.z * -1.0f, dh.x * -1.0f);   // zoic.cpp:1960-1961
+            records[2u * ray + 1u] = make_float4(dh.y * -1.0f, dh.z * -1.0f, w, __builtin_bit_cast(float, (tries > 0 ? 1u : 0u) | (tries << 1) | ((q.flags & 1u) << 6)));
             tir += tally;
             vign += vignetted ? 1u : 0u; succ += vignetted ? 0u : 1u;   // (written as selects: `if ... ++a; else ++b;` became an indexed counter in scratch)
         }
-        if (mine && outcome == 0u && t == 0u) { state[ray].nextTry = q.nextTry + L; state[ray].tirTally = tally; }
+        if (mine && outcome == 0u && t == 0u) { state[ray].nextTry = q.nextTry + static_cast<uint32_t>(R) * L; state[ray].tirTally = tally; }
+        // ... and the block's last lane stands behind the draws of the round's last try: where the next round's lanes step on from
+        if (mine && outcome == 0u && t == L - 1u) { state[ray].rngNext[0] = rng.x; state[ray].rngNext[1] = rng.y; state[ray].rngNext[2] = rng.z; state[ray].rngNext[3] = rng.w; }
         if (mine && outcome == 3u && t == 0u) state[ray].tirTally = tally;
         // the wave's view of who is still open: every block's first lane ORs its ray's bit into the round's masks
         uint32_t *masks = reinterpret_cast<uint32_t *>(stage + kStageMasks);
