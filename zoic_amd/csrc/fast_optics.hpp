@@ -140,21 +140,62 @@ __device__ __forceinline__ FastSurface uniform_surface(const FastSurface &s)
 // the three agree bit for bit on every decision.
 __device__ __forceinline__ float fast_norm2(const V3 &d) { return ffma(d.z, d.z, ffma(d.y, d.y, d.x * d.x)); }
 __device__ __forceinline__ float fast_axis2(const V3 &o) { return ffma(o.y, o.y, o.x * o.x); }
+// a near-planar interface (the stop): its `sign` word is 2R instead of +-1 (lens_system.cpp fill_surfaces)
+__device__ __forceinline__ bool surface_is_flat(const FastSurface &S) { return (__builtin_bit_cast(uint32_t, S.sign) & 0x7fffffffu) != 0x3f800000u; }
 struct FastHit { float w, thc, h2, tca; V3 hit; };
 __device__ __forceinline__ FastHit fast_hit(const FastSurface &S, const V3 &o, float oAxis2, const V3 &u)
 {
     FastHit r;
     const float Lz = S.center - o.z;
-    const float tca = ffma(-o.y, u.y, ffma(Lz, u.z, -(o.x * u.x)));     // L.u with L = (-o.x, -o.y, Lz)
-    const float d2 = ffma(-tca, tca, ffma(Lz, Lz, oAxis2));             // |L|^2 - tca^2, |L|^2 = h^2 of the previous hit + Lz^2
+    float tca, t;
+#if ZOIC_FAST_STABLE_STOP
+    // EXPERIMENT (tables.hpp ZOIC_FAST_STABLE_STOP, off in the product build; DESIGN section 6, profiles/ab_r05/ab_stop.log): another root at the
+    // stop (zoic.cpp:933: radius 0 -> a sphere of |R| ~ 1e4 cm).  t = tca + sgn(R) thc subtracts two numbers of magnitude |R| and leaves
+    // the hit good to ulp(|R|) ~ 1e-3 cm: the clip there is decided by the REFERENCE's rounding noise, which is why the interface
+    // carries a guard band (lens_system.cpp) as wide as FAST's and the reference's hits can differ.  Neither variant narrows it.
+    if (__builtin_expect(surface_is_flat(S), 0)) {          // wave-uniform (S is in SGPRs): a scalar compare and a branch not taken
+        const float twoR = S.sign;                          // flat surfaces carry 2R where the others carry sgn(R) (tables.hpp)
+        const float sgn = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, twoR) & 0x80000000u) | 0x3f800000u);
+#if ZOIC_FAST_STABLE_STOP == 1
+        // Variant 1: the root in its conjugate form, t = C / (tca - sgn(R) thc), C = h0^2 + g (g - 2R), g = (c + R) - o.z -- good to ~2
+        // ulps of t.  FAST/STRICT disagreements at the stop went UP (C4: 5349 -> 9958 of 16.8 M rays): the plain root makes nearly the
+        // same rounding errors as the reference's (same cancellation on the same operands) and they cancel in the comparison; an
+        // accurate hit differs from the reference's by the reference's whole noise.
+        tca = ffma(-o.y, u.y, ffma(Lz, u.z, -(o.x * u.x)));
+        const float d2 = ffma(-tca, tca, ffma(Lz, Lz, oAxis2));
+        r.w = S.radius2 - d2;
+        r.thc = fsqrt_fast(r.w);
+        const float R = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, twoR) - 0x00800000u);
+        const float g = (S.center + R) - o.z;
+        const float C = ffma(g, g - twoR, oAxis2);
+        const float plain = ffma(r.thc, sgn, tca), den = ffma(-r.thc, sgn, tca);
+        t = (tca * sgn < 0.0f) ? C * frcp_fast(den) : plain;
+#else
+        // Variant 2: the reference's OWN operations in its order, one rounding per operator, a correctly rounded root (zoic.cpp:975-991),
+        // on FAST's (o, u).  Disagreements DOWN (C2 582 -> 250, C5 92 -> 40, C4 5349 -> 4433) but their largest margin is unchanged
+        // (one quantum of ulp(|R|): the two arrive with directions a last bit apart, and Lz u.z then rounds one ulp apart), so the
+        // band -- sized by the largest -- and the work list stay as they are, and the extra instructions cost C4 / C5 1-2.5 %.
+        const float Lx = 0.0f - o.x, Ly = 0.0f - o.y;
+        tca = (Lx * u.x + Ly * u.y) + Lz * u.z;
+        const float d2 = ((Lx * Lx + Ly * Ly) + Lz * Lz) - (tca * tca);
+        r.w = S.radius2 - d2;
+        r.thc = ZOIC_SQRT_RN(r.w);                          // (a miss -- w < 0 -- stays a NaN hit: see below)
+        t = tca + r.thc * sgn;
+#endif
+    } else
+#endif
+    {
+        tca = ffma(-o.y, u.y, ffma(Lz, u.z, -(o.x * u.x)));     // L.u with L = (-o.x, -o.y, Lz)
+        const float d2 = ffma(-tca, tca, ffma(Lz, Lz, oAxis2)); // |L|^2 - tca^2, |L|^2 = h^2 of the previous hit + Lz^2
+        // A ray that MISSES the sphere (d2 > radius2, zoic.cpp:981) takes the root of a negative number: thc, the hit point and h^2
+        // are NaN, and every clip test below is written !(h2 <= limit) -- true for NaN -- so the miss needs no compare of its own.
+        // (A ray that ARRIVES as NaN -- a lens sample at the disk mapping's 0/0 centre, zoic.cpp:697-699 -- passes every `>` of the
+        // reference and comes out a NaN success; it is recognised by its NaN tca at the first interface, is_nan_ray.)
+        r.w = S.radius2 - d2;                               // thc^2
+        r.thc = fsqrt_fast(r.w);
+        t = ffma(r.thc, S.sign, tca);
+    }
     r.tca = tca;
-    // A ray that MISSES the sphere (d2 > radius2, zoic.cpp:981) takes the root of a negative number: thc, the hit point and h^2
-    // are NaN, and every clip test below is written !(h2 <= limit) -- true for NaN -- so the miss needs no compare of its own.
-    // (A ray that ARRIVES as NaN -- a lens sample at the disk mapping's 0/0 centre, zoic.cpp:697-699 -- passes every `>` of the
-    // reference and comes out a NaN success; it is recognised by its NaN tca at the first interface, is_nan_ray.)
-    r.w = S.radius2 - d2;                                   // thc^2
-    r.thc = fsqrt_fast(r.w);
-    const float t = ffma(r.thc, S.sign, tca);
     r.hit = V3{ffma(u.x, t, o.x), ffma(u.y, t, o.y), ffma(u.z, t, o.z)};
     r.h2 = ffma(r.hit.y, r.hit.y, r.hit.x * r.hit.x);
     return r;

@@ -265,11 +265,16 @@ void LensSystem::fill_surfaces(KolbTable &t) const
         q.qOffset = static_cast<float>((1.0 - eta * eta) * R * R / (eta * eta));
         q.krScale = static_cast<float>(eta / (std::fabs(R) * R));
         const float relBand = eps * std::fabs(r.radius) / std::sqrt(s.housing2);   // relative to housing2
+        const bool flat = relBand > kGuardMinRelBand;                                // near-planar: in practice the stop
+#if ZOIC_FAST_STABLE_STOP
+        if (flat) q.sign = 2.0f * r.radius;   // fast_hit takes this interface's root in its conjugate form (2R where the others carry sgn(R))
+#endif
+        const float scaleHere = flat ? kGuardScaleFlat : guardScale;
 #if ZOIC_GUARD_ALL
-        const float relAll = guardScale * relBand > kGuardFloorRel ? guardScale * relBand : kGuardFloorRel;
+        const float relAll = scaleHere * relBand > kGuardFloorRel ? scaleHere * relBand : kGuardFloorRel;
         const float band = (guardScale > 0.0f) ? relAll * s.housing2 : 0.0f;
 #else
-        const float band = (relBand > kGuardMinRelBand) ? guardScale * relBand * s.housing2 : 0.0f;
+        const float band = flat ? scaleHere * relBand * s.housing2 : 0.0f;
 #endif
         q.housingLo = q.housingHi = s.housing2;
         if (band > 0.0f) {   // outward rounding: (housingLo, housingHi] contains every h2 with |h2 - housing2| < band

@@ -32,6 +32,11 @@ struct LensRow {
 #define ZOIC_GUARD_SCALE 2.0f   // experiments: -DZOIC_GUARD_SCALE=x (0: no ray is ever listed)
 #endif
 constexpr float kGuardScale = ZOIC_GUARD_SCALE;
+// (experiments: ZOIC_FAST_STABLE_STOP in tables.hpp; -DZOIC_GUARD_SCALE_FLAT=x then sizes the band of a near-planar interface)
+#ifndef ZOIC_GUARD_SCALE_FLAT
+#define ZOIC_GUARD_SCALE_FLAT ZOIC_GUARD_SCALE   // the band of such an interface, in units of eps*|R|/sqrt(housing2)
+#endif
+constexpr float kGuardScaleFlat = ZOIC_FAST_STABLE_STOP ? ZOIC_GUARD_SCALE_FLAT : ZOIC_GUARD_SCALE;
 // share of the sensor square the retry-dead test must classify for the in-kernel completion of such rays to be compiled in
 // (fill_table; 0: for every camera with a LUT, >= 1: never -- experiments: -DZOIC_RETRY_DEAD_MIN_SHARE=x)
 #ifndef ZOIC_RETRY_DEAD_MIN_SHARE

@@ -38,10 +38,19 @@ struct Surface {
 
 // The same interface pre-digested for the FAST kernel (fast_optics.hpp): with a unit direction the Snell step needs
 // no dot product -- cos(incidence) = thc/|R| -- so everything that multiplies thc or thc^2 is folded on the host.
+// EXPERIMENT, off in the product build.  Near-planar interfaces (noise estimate eps*|R|/sqrt(housing2) above kGuardMinRelBand,
+// lens_system.hpp: the stop, traced as a sphere of |R| ~ 1e4 cm, zoic.cpp:933): how FAST takes the hit there (fast_optics.hpp fast_hit)
+//   0  like everywhere else (the product)
+//   1  the root in its conjugate form: accurate -- and MORE disagreements with the reference
+//   2  the reference's own operations in the reference's order: fewer disagreements, none smaller: the band cannot shrink
+// (profiles/ab_r05/ab_stop.log)
+#ifndef ZOIC_FAST_STABLE_STOP
+#define ZOIC_FAST_STABLE_STOP 0
+#endif
 struct FastSurface {
     float center;        // sphere centre z
     float radius2;       // R^2
-    float sign;          // sgn(R)
+    float sign;          // sgn(R)  (ZOIC_FAST_STABLE_STOP builds: 2R on a near-planar interface)
     float housing2;      // clip limit on x^2+y^2 (same f32 as Surface::housing2)
     float eta;           // n1/n2
     float qOffset;       // (1 - eta^2) R^2 / eta^2 : q = thc^2 + qOffset, 1 - cs2 = (eta/R)^2 q, TIR <=> q < 0
