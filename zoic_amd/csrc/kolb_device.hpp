@@ -13,7 +13,10 @@
 
 namespace zoic {
 
-constexpr int kRefillBlock = 256;
+#ifndef ZOIC_REFILL_BLOCK
+#define ZOIC_REFILL_BLOCK 256   // experiments: -DZOIC_REFILL_BLOCK=128 / 512 (with -DZOIC_GRID_BLOCKS=4096 / 1024 for the same number of waves)
+#endif
+constexpr int kRefillBlock = ZOIC_REFILL_BLOCK;
 constexpr int kWavesPerBlock = kRefillBlock / 64;
 constexpr uint32_t kLutLdsWords = 2 * kLutEntries;  // (maxScale, centroid.x) pairs at the start of the dynamic LDS
 #ifndef ZOIC_MIN_SEARCHING

@@ -221,6 +221,9 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #if ZOIC_STORE_TRANSPOSED && ZOIC_POOL_SLIM
 #error "ZOIC_STORE_TRANSPOSED stages in the upper half of pool1's float4 array: not with ZOIC_POOL_SLIM"
 #endif
+#ifndef ZOIC_STORE_NT
+#define ZOIC_STORE_NT 0   // experiments: 1 = the IMAGE kernels' records leave as non-temporal stores (they never come back; the bokeh table they evict does), 2 = every kernel's
+#endif
 #ifndef ZOIC_SEARCH_DRAWS
 #define ZOIC_SEARCH_DRAWS 2   // lens draws the retry search of the IMAGE kernels samples per round (one wait for all their records); measured on C3: 1 -> 38.8, 2 -> 41.1, 3 -> 40.4, 4 -> 39.6 Grays/s
 #endif
@@ -607,7 +610,11 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 __builtin_amdgcn_wave_barrier();
             } else
 #endif
-            if (finished) store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);   // zoic.cpp:1960-1961
+            if (finished) {
+                if constexpr (ZOIC_STORE_NT == 2 || (ZOIC_STORE_NT == 1 && IMAGE))
+                    store_ray_record_nt(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);
+                else store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);   // zoic.cpp:1960-1961
+            }
         }
         ZOIC_MARK(7)   // finish: counters + record store
         if constexpr (GUARD) {

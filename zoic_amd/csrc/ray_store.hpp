@@ -26,6 +26,15 @@ __device__ __forceinline__ void store_ray_record(RayRecord *out, uint64_t i, flo
     p[1] = make_float4(dy, dz, w, __builtin_bit_cast(float, flags));
 }
 
+// the same with non-temporal stores (experiments: -DZOIC_STORE_NT, kolb_pool_body.hpp)
+__device__ __forceinline__ void store_ray_record_nt(RayRecord *out, uint64_t i, float ox, float oy, float oz, float dx, float dy,
+                                                    float dz, float w, uint32_t flags)
+{
+    float4 *p = reinterpret_cast<float4 *>(out + i);
+    nt_store(p, make_float4(ox, oy, oz, dx));
+    nt_store(p + 1, make_float4(dy, dz, w, __builtin_bit_cast(float, flags)));
+}
+
 // Wave-cooperative store for kernels where lane l of a wave owns ray (waveBase + l): the 64 records (2 KiB) are
 // transposed through LDS so that each of the two store instructions writes one contiguous, fully coalesced KiB
 // (lane l writes 16-byte piece k*64 + l) instead of 64 half-sectors at a 32-byte stride.  `stage` = 128 float4 of
