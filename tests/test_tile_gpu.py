@@ -45,10 +45,11 @@ def same_rows(a, b):
 
 
 @pytest.mark.parametrize("cfg,where", [("C1", 0.4), ("C2", 0.08), ("C3", 0.3), ("C4", 0.5), ("C5", 0.12)])
-@pytest.mark.parametrize("precision", [PRECISION_STRICT, PRECISION_FAST])
+@pytest.mark.parametrize("precision", [PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_UNCHECKED])
 def test_a_tile_equals_the_arnold_batch_call_bit_for_bit(gpu, cfg, where, precision):
     """n in {1, 63, 64, 65, 4096, 65536}: one lane, a ragged batch, a full batch, one lane over, a bucket, the largest tile --
-    against zoic_create_rays_arnold (launch-based: GUARD + listed kernels in FAST) on the same samples and ray indices.  The slabs
+    against zoic_create_rays_arnold (launch-based: GUARD + listed kernels in FAST, the plain FAST kernel unchecked) on the same samples
+    and ray indices -- the resident kernels have an instantiation of their own per precision mode and interface count.  The slabs
     hold first-try rays, retried rays, retry-dead rays (C2, C5), dead pixels (C5) and rays the FAST mode cannot decide (C4)."""
     cam = camera(cfg, precision)
     a, _s, base = inputs_of(cfg, 65536, where)
