@@ -75,12 +75,7 @@ __device__ __forceinline__ void store_uncached(uint4 *p, uint4 q)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
-__device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have landed before any lane reads another lane's words
-{
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-}
+// (wave_lds_fence: kolb_listed_body.hpp)
 
 // ---- RAYTRACED, zoic.cpp:1850-1964, for the rays a wave holds: the TRIES of a ray side by side ------------------------------------
 // A resident wave is alone on its SIMD: what a call waits for is the longest CHAIN of dependent instructions, not their number (a
