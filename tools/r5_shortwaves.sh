@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r5_shortwaves.sh -- the listed kernel's short-list path at W = 4 / 8 / 16 / 32 rays per wave (ZOIC_SHORT_WAVE_RAYS) against the old path
+# tools/r5_shortwaves.sh (needs the build of commit d9afcf9) -- the listed kernel's short-list path at W = 4 / 8 / 16 / 32 rays per wave (ZOIC_SHORT_WAVE_RAYS) against the old path
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 run() {  # label
   for c in C2 C3 C5; do

@@ -14,10 +14,9 @@ int launch_kolb_listed(const KolbTable &table, const BokehTables &bokeh, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint32_t ldsWords = kolb_image_cells(table, bokeh) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
     const size_t lds = static_cast<size_t>(ldsWords + kLutLdsWords + kWavesPerBlock * kListedWaveWords) * sizeof(float);
-    static const uint32_t shortWaveRays = [] { const char *e = std::getenv("ZOIC_SHORT_WAVE_RAYS"); const int v = e ? std::atoi(e) : 0; return (v == 4 || v == 8 || v == 16 || v == 32) ? static_cast<uint32_t>(v) : 0u; }();   // experiments only
 #define ZOIC_LAUNCH_LISTED(NS_)                                                                                                          \
     hipLaunchKernelGGL((kolb_listed_kernel<NS_>), dim3(grid), dim3(kRefillBlock), lds, st, table, bokeh, d_samples, d_rng, rayBase, m, out, \
-                       d_counters, d_redoCursor, ldsWords, shortWaveRays, 0u, kMinSearching, d_redoList, d_redoCount, static_cast<unsigned int *>(nullptr))
+                       d_counters, d_redoCursor, ldsWords, 0u, 0u, kMinSearching, d_redoList, d_redoCount, static_cast<unsigned int *>(nullptr))
     switch (table.lensCount) {
     case 7: ZOIC_LAUNCH_LISTED(7); break;
     case 8: ZOIC_LAUNCH_LISTED(8); break;

@@ -271,180 +271,14 @@ __device__ __forceinline__ void listed_short_hybrid(const KolbTable &T, const Bo
     }
 }
 
-// Short lists, second version (round 5): listed_short_hybrid spends G lanes on a ray from the start, and G - 1 of them sit through
-// the reference's set-up and try 0 -- ~1550 of a listed ray's ~2500 instructions -- which only lane 0 of the group needs: a 32 K-ray
-// list is 4096 waves x 1550 instructions of STRICT code at one live lane in eight, four waves to a SIMD, and that (not the length of
-// one ray's chain) was most of the listed kernel's 44 us behind a 460 us TESSAR frame.  Here a wave takes W = 16 or 32 listed rays:
-//   * the reference's set-up and try 0 for all of them at once, one ray per lane (dead pixels and first-try successes end here:
-//     half of the rays that were listed AT the stop get through it in the reference's arithmetic);
-//   * then ROUNDS over the rays still open, like the resident tile workers' (mailbox.hip): each round shares all 64 lanes among
-//     them -- L = 64 / #open lanes per ray, FAST-guarded tries nextTry ... nextTry + L - 1 side by side through one predicated trace,
-//     a try too close to call again in the reference's arithmetic on the spot, the first success in try order wins, try 26 hands
-//     out its partial state (zoic.cpp:1927 / 1951).  Ray state travels through the wave's LDS between rounds.
-// The same device functions per try as listed_group_round and the long lists' passes: the same bits whichever evaluates a ray.
-#ifndef ZOIC_LISTED_SHORT_WAVES
-#define ZOIC_LISTED_SHORT_WAVES 1   // 0: listed_short_hybrid (rounds 3-4) for A/B
-#endif
-__device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have landed before any lane reads another lane's words
+// (Round 5 tried the short lists the other way round -- the reference's set-up and try 0 at one ray per LANE, then rounds sharing the wave's
+// lanes among the rays still open -- parity green and not faster: with 64 tries in a wave's round the rare per-lane paths (a try too close
+// to call, a failed try 26's partial state) run in most rounds.  profiles/ab_r05/ab_listed_short_waves.log; the code is commit d9afcf9.)
+__device__ __forceinline__ void wave_lds_fence()   // the wave's LDS writes have landed before any lane reads another lane's words (mailbox.hip)
 {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ uint32_t short_wave_rays_for(uint32_t n)   // rays a wave takes at once
-{
-    const uint32_t forced = ZOIC_KARG(chunkRays);   // (experiments: ZOIC_SHORT_WAVE_RAYS in the environment, kolb_listed.hip; 0 in the product)
-    if (forced != 0u) return forced;
-    return n <= 16384u ? 16u : 32u;
-}
-struct ListedOpenRay {   // 16 dwords in the wave's LDS stage
-    uint32_t idx, nextTry;
-    float o0x, o0y, maxScale, translation, sn, cs;
-    uint32_t rngNext[4];                               // the ray's retry stream at the draws of try nextTry (>= 1)
-    uint32_t lutMiss, pad[3];
-};
-static_assert(sizeof(ListedOpenRay) == 64, "stage layout");
-template <int NS>
-__device__ __forceinline__ void listed_short_waves(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds,
-                                                   const float4 *__restrict__ samples, uint32_t n, RayRecord *__restrict__ out, float *stageWords)
-{
-    constexpr uint32_t kOut = static_cast<uint32_t>(kMaxTries) + 1u;
-    const uint32_t W = short_wave_rays_for(n);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wavesTotal = gridDim.x * kWavesPerBlock, waveId = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const uint32_t *list = ZOIC_KARG(redoList);
-    const uint4 *states = ZOIC_KARG(rngStates);
-    const uint64_t rayBase = ZOIC_KARG(rayBase);
-    ListedOpenRay *stage = reinterpret_cast<ListedOpenRay *>(stageWords);
-    uint32_t *masks = reinterpret_cast<uint32_t *>(stageWords + 32u * 16u);
-    uint32_t succ = 0, vign = 0, tir = 0;   // per lane; reduced at the end
-    for (uint32_t first = waveId * W; first < n; first += wavesTotal * W) {
-        // ---- the reference's set-up and try 0, one ray per lane (zoic.cpp:1853-1925) ---------------------------------------------------
-        const bool have = lane < W && first + lane < n;
-        uint32_t open = 0;
-        {
-            const uint32_t idx = list[have ? first + lane : first];
-            const float4 s = samples[idx];
-            const RaySetup rs = setup_ray<true>(T, lutLds, s.x, s.y);
-            Rng rng;
-            if (states) { const uint4 q = states[idx]; rng = Rng{q.x, q.y, q.z, q.w}; }
-            else rng = rng_for_ray(T.seed, rayBase + idx);
-            const bool deadPixel = listed_dead_pixel(T, B, bokehLds, rs, s);
-            V3 o{rs.o0x, rs.o0y, T.originShift}, d;
-            V2 lens = lens_sample<true>(T, B, bokehLds, s.z, s.w);   // zoic.cpp:1870
-            if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};
-            else {                                                    // zoic.cpp:1913-1924: x-only translation
-                lens.x *= rs.maxScale; lens.y *= rs.maxScale;
-                lens.x += rs.translation;
-                const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
-                d = V3{rx - o.x, ry - o.y, T.dirZ};
-            }
-            uint32_t tirTry = 0;
-            bool ok = false;
-            if (have) ok = listed_strict_try(T, o, d, tirTry);
-            // a dead pixel whose try 0 failed: 26 identical failures follow -- ITS (STRICT) state with weight 0 and 27 x its TIR bump
-            const bool deadEnd = have && !ok && deadPixel;
-            if (have && (ok || deadEnd)) {
-                float w = ok ? 1.0f : 0.0f;
-                if (T.exposureOn) w *= T.exposureMul;                  // zoic.cpp:1981-1987
-                store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
-                                 deadEnd ? (1u | (kOut << 1) | ((rs.flags & 1u) << 6)) : ((rs.flags & 1u) << 6));
-                tir += deadEnd ? (kOut + 1u) * tirTry : 0u;
-                succ += ok ? 1u : 0u; vign += ok ? 0u : 1u;
-            }
-            const bool stays = have && !ok && !deadEnd;
-            if (stays) {
-                tir += tirTry;                                         // try 0 ran and failed: its bump counts
-                ListedOpenRay &q = stage[lane];
-                q.idx = idx; q.nextTry = 1u; q.o0x = rs.o0x; q.o0y = rs.o0y; q.maxScale = rs.maxScale; q.translation = rs.translation; q.sn = rs.sn; q.cs = rs.cs;
-                q.rngNext[0] = rng.x; q.rngNext[1] = rng.y; q.rngNext[2] = rng.z; q.rngNext[3] = rng.w;
-                q.lutMiss = rs.flags & 1u;
-            }
-            open = static_cast<uint32_t>(__ballot(stays));             // (W <= 32: the low word)
-        }
-        wave_lds_fence();
-        // ---- rounds: the open rays share the wave's lanes, tries nextTry ... nextTry + L - 1 of a ray side by side -----------------------
-        while (open != 0u) {
-            const uint32_t nOpen = static_cast<uint32_t>(__builtin_popcount(open));
-            uint32_t L = 32u;
-            while (L * nOpen > 64u) L >>= 1;                           // >= 2: at most 32 rays are open
-            const uint32_t pos = lane / L, t = lane & (L - 1u), blockBase = lane & ~(L - 1u);
-            uint32_t m = open;
-            for (uint32_t i = 0; i < pos && m != 0u; ++i) m &= m - 1u;
-            const bool mine = pos < nOpen && m != 0u;
-            const uint32_t ray = static_cast<uint32_t>(__builtin_ctz(mine ? m : open));
-            const ListedOpenRay q = stage[ray];
-            const uint32_t k = q.nextTry + t;                          // this lane's try (>= 1)
-            const bool valid = mine && k <= kOut;
-            const V3 o0{q.o0x, q.o0y, T.originShift};
-            Rng rng{q.rngNext[0], q.rngNext[1], q.rngNext[2], q.rngNext[3]};
-            for (uint32_t a = 0; a < t; ++a) { (void)xor128(rng); (void)xor128(rng); }
-            const float u = rng_unit(xor128(rng));                     // zoic.cpp:1930
-            const float v = rng_unit(xor128(rng));
-            V3 o = o0;
-            V3 d = retry_direction(T, lens_sample<false>(T, B, bokehLds, u, v), q.o0x, q.o0y, q.maxScale, q.translation, q.sn, q.cs);
-            uint32_t tirTry = 0;
-            bool ok = false, unsure = false;
-            if constexpr (NS > 0) {
-                // the search's interface-0 test first, exactly as a B pass takes it (a try that dies there leaves (o, d) untouched)
-                bool near0 = false;
-                const bool pass0 = interface0_clear_fast<true>(load_surface<false>(kernarg_fast_surfaces(), 0), o, d, near0);
-                const bool cand = valid && pass0 && !near0;
-                unsure = valid && near0;
-                unsigned long long tirMask, unsureMask;
-                V3 ot = o, dt = d;
-                const unsigned long long alive = trace_lens_fast_pred<NS, true>(kernarg_fast_surfaces(), ot, dt, __ballot(cand), tirMask, unsureMask);
-                if (cand) {
-                    ok = mask_bit(alive, lane);
-                    tirTry = mask_bit(tirMask, lane) ? 1u : 0u;
-                    unsure |= mask_bit(unsureMask, lane);
-                    if (ok) { o = ot; d = dt; }
-                    else if (!unsure && k == kOut) {   // only try 26's partial state is ever handed out
-                        uint32_t ignored = 0;
-                        (void)trace_lens_fast_rolled(T, o, d, ignored);
-                    }
-                }
-            } else if (valid) ok = trace_lens_fast_rolled(T, o, d, tirTry, &unsure);
-            if (valid && unsure) {   // too close to call: that try again in the reference's arithmetic (same draws), and THAT result stands
-                o = o0; tirTry = 0;
-                d = listed_retry_direction_strict(T, B, bokehLds, u, v, q.o0x, q.o0y, q.maxScale, q.translation, q.sn, q.cs);
-                ok = listed_strict_try(T, o, d, tirTry);
-            }
-            // the ray's decision, in try order, by the L lanes of its block
-            const uint32_t blockBits = L >= 32u ? 0xffffffffu : ((1u << L) - 1u);
-            const uint32_t okB = static_cast<uint32_t>(__ballot(valid && ok) >> blockBase) & blockBits;
-            const uint32_t winner = okB ? static_cast<uint32_t>(__builtin_ctz(okB)) : 32u;   // lowest try that got through
-            if (valid && t < winner) tir += tirTry;                    // only the tries the reference actually ran
-            const bool last = k == kOut;                               // try 26 failed as well: weight 0, ITS partial state
-            const bool finished = winner < 32u || q.nextTry + L > kOut;
-            if (valid && (t == winner || (winner == 32u && last))) {
-                const bool okRay = t == winner && !last;
-                float w = okRay ? 1.0f : 0.0f;
-                if (T.exposureOn) w *= T.exposureMul;                  // zoic.cpp:1981-1987
-                store_ray_record(out, q.idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w,   // zoic.cpp:1960-1961
-                                 1u | (k << 1) | (q.lutMiss << 6));
-                succ += okRay ? 1u : 0u; vign += okRay ? 0u : 1u;
-            }
-            // still open: the next round's lanes step on from behind this round's last try
-            if (mine && !finished && t == L - 1u) {
-                stage[ray].nextTry = q.nextTry + L;
-                stage[ray].rngNext[0] = rng.x; stage[ray].rngNext[1] = rng.y; stage[ray].rngNext[2] = rng.z; stage[ray].rngNext[3] = rng.w;
-            }
-            if (lane == 0u) masks[0] = 0u;
-            wave_lds_fence();
-            if (mine && !finished && t == 0u) atomicOr(masks, 1u << ray);
-            wave_lds_fence();
-            open = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(masks[0])));
-            wave_lds_fence();
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) { succ += __shfl_xor(succ, off, 64); vign += __shfl_xor(vign, off, 64); tir += __shfl_xor(tir, off, 64); }
-    DeviceCounters *counters = counter_set(ZOIC_KARG(counters));
-    if (counters && lane == 0) {
-        if (succ) atomicAdd(&counters->succes, static_cast<unsigned long long>(succ));
-        if (vign) atomicAdd(&counters->vignetted, static_cast<unsigned long long>(vign));
-        if (tir) atomicAdd(&counters->tir, static_cast<unsigned long long>(tir));
-    }
 }
 
 template <int NS>
@@ -456,11 +290,7 @@ __device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const Bokeh
     if (n == 0u) return;
     // 64-entry chunks while the list is short (every wave gets work), 256 once it could feed the chip several times over
     const uint32_t redoChunk = n > (1u << 20) ? 256u : 64u;
-#if ZOIC_LISTED_SHORT_WAVES
-    const uint32_t shortRaysPerWave = short_wave_rays_for(n);
-#else
     const uint32_t shortGroup = short_group_for(n), shortRaysPerWave = 64u / shortGroup;
-#endif
     const uint32_t totalChunks = n <= kShortList ? (n + shortRaysPerWave - 1u) / shortRaysPerWave : (n + redoChunk - 1u) / redoChunk;
     if (blockIdx.x * kWavesPerBlock >= totalChunks) return;   // whole workgroup: nothing listed for it
     const uint32_t redoChunksPerPart = (totalChunks + kCursorParts - 1u) / kCursorParts;
@@ -477,13 +307,9 @@ __device__ __forceinline__ void kolb_listed_body(const KolbTable &T, const Bokeh
     __syncthreads();
     const float2 *lutLds = reinterpret_cast<const float2 *>(zoicDynLds);
     if (n <= kShortList) {
-#if ZOIC_LISTED_SHORT_WAVES
-        listed_short_waves<NS>(T, B, lutLds, bokehLds, samples, n, out, zoicDynLds + kLutLdsWords + ldsWords + wave * kListedWaveWords);
-#else
         if (shortGroup == 16u) listed_short_hybrid<NS, 16u>(T, B, lutLds, bokehLds, samples, n, out);
         else if (shortGroup == 8u) listed_short_hybrid<NS, 8u>(T, B, lutLds, bokehLds, samples, n, out);
         else listed_short_hybrid<NS, 4u>(T, B, lutLds, bokehLds, samples, n, out);
-#endif
         return;
     }
 
