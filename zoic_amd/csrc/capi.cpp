@@ -343,6 +343,13 @@ void Mailbox::release()
                              t[8] * 0.01 / t[4], t[9] * 0.01, t[10] * 0.01 / t[4], t[11] * 0.01);
             if (t[4]) std::fprintf(stderr, "worker batches that started > 8 us after the request: %llu (mean batch index %.1f, %llu of them NOT the first batch after a wake-up); flagged > 25 us: %llu\n", t[12],
                                    t[12] ? double(t[13]) / t[12] : 0.0, t[14], t[15]);
+            unsigned long long g[16] = {};
+            if (read_tile_dbg(g) == 0 && g[10])
+                std::fprintf(stderr, "RAYTRACED batches by rounds 0..7+: %llu %llu %llu %llu %llu %llu %llu %llu; with a listed ray: %llu (listed part %.2f us each); rounds part %.2f us per batch; "
+                             "open after round 0: %.2f rays per batch; batches with more than 8 open after round 0: %llu (their rounds part: %.2f us each)\n",
+                             g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[8] ? g[9] * 0.01 / g[8] : 0.0,
+                             g[10] * 0.01 / (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] ? g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] : 1),
+                             double(g[12]) / (g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] ? g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] : 1), g[13], g[13] ? g[14] * 0.01 / g[13] : 0.0);
             for (int o = 0; o < 8; o += 4)
                 if (t[o])
                     std::fprintf(stderr, "tile timing (%s waves): %llu batches, input %.2f us, rays %.2f us, output %.2f us per batch\n", o ? "worker" : "slot", t[o],

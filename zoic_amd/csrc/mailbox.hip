@@ -53,6 +53,12 @@
 
 namespace zoic {
 
+#ifdef ZOIC_TILE_TIMING
+// timing builds only: [0..7] batches by number of rounds (7 = seven or more), [8] batches with a listed ray, [9] ticks in the listed part, [10] ticks in
+// the rounds, [12] sum of rays open after round 0, [13] batches with more than 8 open after round 0, [14] their ticks in the rounds
+__device__ unsigned long long g_tileDbg[16];
+#endif
+
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -149,14 +155,23 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
     }
     wave_lds_fence();
     uint32_t open = (cnt >= 32u ? 0xffffffffu : ((1u << cnt) - 1u)) & ~listedMask;   // wave-uniform: rays with tries to run
+#ifdef ZOIC_TILE_TIMING
+    const unsigned long long dbgT1 = wall_clock64();
+    uint32_t dbgRounds = 0, dbgOpen1 = 0;
+#endif
     // R = tries per LANE.  Measured with R = 2 where the unrolled FAST trace exists (lane t of a block: tries nextTry + t and nextTry + L + t,
     // round 0 covering tries 0 ... 7) [MI355X, profiles/ab_r05/tile_latency_v8.txt, _v9.txt]: a 4096-sample tile 29.1 -> 28.5 us, but a
     // 64-sample tile 17.3 -> 19.6 and the per-sample call 7.1 -> 8.6 us.  A lone wave is not waiting for its dependent instructions -- a wave64
     // VALU instruction issues every 4 cycles whether or not it depends on the one before -- it is paying for every instruction it issues
     // (and for every taken branch and scalar-load wait), so a second try in the same lane costs what it would cost in another round.  R = 1.
+    // (R = 2 only in a later round that finds more than eight rays open -- four lanes a ray -- bought nothing either: tile_latency_v11.txt.)
     constexpr int R = 1;
     bool firstRound = true;
     while (open != 0u) {
+#ifdef ZOIC_TILE_TIMING
+        if (dbgRounds == 1u) dbgOpen1 = static_cast<uint32_t>(__builtin_popcount(open));
+        ++dbgRounds;
+#endif
         // ---- this round's lanes: L per open ray (4 in round 0, up to 32 / R for the stragglers) ----------------------------------------
         // (round 0 stays at four lanes per ray however few rays there are: a lane steps the ray's stream over the draws of the tries in
         // front of its own first, and 25 of those in front of a single sample's first round cost its median call 1.2 us for tries 95 % of
@@ -307,6 +322,9 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
         open = stillOpen;
         wave_lds_fence();
     }
+#ifdef ZOIC_TILE_TIMING
+    const unsigned long long dbgT2 = wall_clock64();
+#endif
     // ---- retry-dead rays whose try 0 failed: the state of the last draw, one lane each ------------------------------------------------------
     if (deadEndMask != 0u) {
         uint32_t m = deadEndMask;
@@ -357,6 +375,16 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
             }
         }
     }
+#ifdef ZOIC_TILE_TIMING
+    if (lane == 0u && cnt > 1u) {
+        const unsigned long long dbgT3 = wall_clock64();
+        atomicAdd(&g_tileDbg[dbgRounds < 7u ? dbgRounds : 7u], 1ull);
+        if (listedMask != 0u) { atomicAdd(&g_tileDbg[8], 1ull); atomicAdd(&g_tileDbg[9], dbgT3 - dbgT2); }
+        atomicAdd(&g_tileDbg[10], dbgT2 - dbgT1);
+        atomicAdd(&g_tileDbg[12], static_cast<unsigned long long>(dbgOpen1));
+        if (dbgOpen1 > 8u) { atomicAdd(&g_tileDbg[13], 1ull); atomicAdd(&g_tileDbg[14], dbgT2 - dbgT1); }
+    }
+#endif
     wave_lds_fence();
 }
 
@@ -755,6 +783,13 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
 }
 
 }  // namespace
+
+#ifdef ZOIC_TILE_TIMING
+int read_tile_dbg(unsigned long long *out16)
+{
+    return static_cast<int>(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tileDbg), 16 * sizeof(unsigned long long)));
+}
+#endif
 
 int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, void *d_mapped,
                    MailDeviceState *d_state, DeviceCounters *d_counters, uint32_t workerGroups, void *stream)

@@ -95,6 +95,9 @@ struct MailDeviceState {
     unsigned long long timing[32];            // -DZOIC_TILE_TIMING builds only: 10 ns ticks per region of a batch, summed over all waves (tools/)
 };
 
+#ifdef ZOIC_TILE_TIMING
+int read_tile_dbg(unsigned long long *out16);   // timing builds: mailbox.hip's g_tileDbg
+#endif
 int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTables &bokeh, int model, int mode, void *d_mapped,
                    MailDeviceState *d_state, DeviceCounters *d_counters, uint32_t workerGroups, void *stream);
 
