@@ -545,15 +545,18 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     }
                     if (lane < parts) store_dev(&st->tickets[slot].part[lane].next, (static_cast<unsigned long long>(seq) << 32) | (lane == 0u ? 1ull : 0ull));
-                    if (lane == 0) {
-                        (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // a woken worker finds the counters and the bit
-                    }
+                    // (the descriptor is fenced in front of the counters: whoever draws a ticket of this generation MUST find it, or the
+                    // ticket -- a batch -- is lost.  The counters and the bit are NOT fenced in front of the wake lines: a woken worker acts on
+                    // them a poll and an atomic's round trip later, and one that still draws a stale ticket only goes back to sleep -- a lost
+                    // wake-up costs time, the slot's wave hands its tile's batches out itself in the end.  The fence here, and the returning atomic
+                    // that rotated the first worker to wake, cost every tile ~1.5 us of hand-off.)
+                    if (lane == 0) (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (workerWaves != 0u) {
                         const uint32_t wakeN = batches - 1u < workerWaves ? batches - 1u : workerWaves;
-                        uint32_t at = 0;
-                        if (lane == 0) at = __hip_atomic_fetch_add(control + 8, wakeN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        at = first_lane(at);
+                        // the first worker to wake: another stretch of the wake lines per slot and per tile, so that tiles of different
+                        // render threads mostly wake different waves (two tiles on one worker: the later wake wins, the other tile's batch
+                        // is drawn by whoever runs dry first)
+                        const uint32_t at = (slot * 61u + seq * 251u) % workerWaves;
                         const unsigned long long tag = (static_cast<unsigned long long>(static_cast<uint32_t>(now) | 1u) << 32) | slot;
                         // the i-th woken worker is meant for batch i + 1: it starts on that batch's partition (partition 0 is one batch
                         // short -- this wave's -- and every partition gets exactly as many workers as it has batches)
