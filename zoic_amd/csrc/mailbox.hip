@@ -28,7 +28,7 @@
 //     84-byte output rows leave as coalesced dword stores (whole rows, as zoic_create_rays_arnold writes them); the wave releases
 //     them at system scope and then writes the batch's FLAG -- the tile's number -- in mapped host memory.  The render thread waits
 //     for all flags of its tile: no counter, no last wave, nobody waits for anybody on the device.  No launch, no stream, no
-//     synchronise: a 4096-sample tile is answered in 25-40 us (thin lens: 19 us) where a launch-based call took 76-122, and 16
+//     synchronise: a 4096-sample tile is answered in 22-28 us (thin lens: 18 us) where a launch-based call took 76-122, and 16
 //     render threads with 65536-sample tiles run at the PCIe rate of the rows (bench.py host_path.tile);
 //   * the rays of a batch: kolb_wave_rays below (the tries of a ray side by side: a resident wave is alone on its SIMD and waits
 //     for its longest dependent chain, not for its instruction count);
@@ -84,9 +84,9 @@ __device__ __forceinline__ void store_uncached(uint4 *p, uint4 q)
 // (wave_lds_fence: kolb_listed_body.hpp)
 
 // ---- RAYTRACED, zoic.cpp:1850-1964, for the rays a wave holds: the TRIES of a ray side by side ------------------------------------
-// A resident wave is alone on its SIMD: what a call waits for is the longest CHAIN of dependent instructions, not their number (a
-// lone wave retires an instruction every ~10 cycles).  The reference's loop -- trace, and while the trace fails and tries <= 25 draw
-// the next lens sample -- is such a chain, up to 27 traces long; with one ray per lane all 64 rays of a wave waited for the
+// A resident wave is alone on its SIMD: what a call waits for is the instructions on its longest PATH -- every one of them, every taken
+// branch, every scalar-load and LDS wait: ~10 cycles apiece -- not the number of lanes that execute them.  The reference's loop -- trace,
+// and while the trace fails and tries <= 25 draw the next lens sample -- is such a path, up to 27 traces long; with one ray per lane all 64 rays of a wave waited for the
 // unluckiest (measured: 39 us for 64 samples of a double Gauss at f/2, 10 us for ONE sample), and a tile waits for its unluckiest
 // wave.  The tries of a ray are independent given its retry stream (try k >= 1 uses draws 2(k-1), 2(k-1)+1), so a wave holds
 // kKolbBatch = 16 rays and runs ROUNDS:
