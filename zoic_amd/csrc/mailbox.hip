@@ -538,7 +538,10 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                         store_dev4(J, make_uint4(lane_word(line.x, 0), lane_word(line.y, 0), jobN, seq));
                         store_dev4(J + 1, make_uint4(lane_word(line.x, 1), lane_word(line.y, 1), lane_word(line.z, 1), seq));
                         store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts | (jobRays << 16), seq));
-                        store_dev(&st->tickets[slot].partsLeft, parts);
+                        {   // the partitions that hold a batch at all (ceil(batches / parts) per partition can leave the last ones empty)
+                            const uint32_t per0 = (batches + parts - 1u) / parts, live = (batches + per0 - 1u) / per0;
+                            store_dev(&st->tickets[slot].partMask, live >= 32u ? 0xffffffffu : ((1u << live) - 1u));
+                        }
 #ifdef ZOIC_TILE_TIMING
                         store_dev(reinterpret_cast<unsigned long long *>(st->jobs + slot) + 6, static_cast<unsigned long long>(now));
 #endif
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                         // the first worker to wake: another stretch of the wake lines per slot and per tile, so that tiles of different
                         // render threads mostly wake different waves (two tiles on one worker: the later wake wins, the other tile's batch
                         // is drawn by whoever runs dry first)
-                        const uint32_t at = (slot * 61u + seq * 251u) % workerWaves;
+                        const uint32_t at = (slot * 257u + seq * 61u) % workerWaves;
                         const unsigned long long tag = (static_cast<unsigned long long>(static_cast<uint32_t>(now) | 1u) << 32) | slot;
                         // the i-th woken worker is meant for batch i + 1: it starts on that batch's partition (partition 0 is one batch
                         // short -- this wave's -- and every partition gets exactly as many workers as it has batches)
@@ -572,14 +575,25 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             else if (curSlot != kNoSlot) jobSlot = curSlot;
             else {
                 if (scanMask) {   // nothing left of the tile this wave was on: any other posted tile?
-                    const unsigned long long mask = first_lane64(load_dev(workMask));
-                    if (mask != 0ull) {
+                    // A slot's bit says "batches left to hand out"; its partition word says WHERE.  Both are loads: a wave that runs dry costs the
+                    // tiles still at work no ticket atomic until it knows a partition that has a batch for it, and the waves that run dry
+                    // together (a tile's 255 workers, all at once) spread over the slots and partitions by their own number -- they used to
+                    // fall on partition 0 of the first posted slot one same-address atomic after the other, in front of that tile's own workers.
+                    unsigned long long mask = first_lane64(load_dev(workMask));
+                    bool found = false;
+                    for (uint32_t tries = 0; mask != 0ull && tries < 4u && !found; ++tries) {
                         const uint32_t r = waveId & 63u;   // every worker starts its search at another slot
                         const unsigned long long rot = r ? ((mask >> r) | (mask << (64u - r))) : mask;
-                        curSlot = (static_cast<uint32_t>(__builtin_ctzll(rot)) + r) & 63u;
-                        curPart = 0; partsTried = 0;   // (partition 0 exists whatever the tile's size)
-                        continue;
+                        const uint32_t cand = (static_cast<uint32_t>(__builtin_ctzll(rot)) + r) & 63u;
+                        const uint32_t live = first_lane(load_dev(&st->tickets[cand].partMask));
+                        if (live != 0u) {
+                            const uint32_t q = (waveId >> 6) & 31u;
+                            const uint32_t rotp = q ? ((live >> q) | (live << (32u - q))) : live;
+                            curSlot = cand; curPart = (static_cast<uint32_t>(__builtin_ctz(rotp)) + q) & 31u; partsTried = 0;
+                            found = true;
+                        } else mask &= ~(1ull << cand);   // (its last batches are being drawn: nothing for this wave there)
                     }
+                    if (found) continue;
                     scanMask = false;
                     if (leaving) break;   // exit flag: only with nothing left to hand out
                 }
@@ -620,19 +634,26 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             if (!sameTile || curPart >= parts || batch >= hi) {
                 // a stale ticket (the tile has been handed out: its counters belong to nobody, or to the next tile -- whose descriptor
                 // then differs) or a partition that is empty: on to the next partition; after all of them, the tile is done with
-                // (a look at the work mask first: once the tile's bit is gone every partition is empty -- one load instead of an atomic per
-                // remaining partition from each of the tile's workers)
+                // (measured with four render threads: a worker used to walk the partitions one ticket atomic and one look at the work mask at a
+                // time -- ~1.7 us each, up to 31 of them behind every batch it had finished -- and a new tile's batches started 83 us late)
                 ++partsTried;
-                const bool gone = !sameTile || partsTried >= parts || ((first_lane64(load_dev(workMask)) >> jobSlot) & 1ull) == 0ull;
+                bool gone = !sameTile || partsTried > parts + 2u;
+                uint32_t live = 0;
+                if (!gone) { live = first_lane(load_dev(&st->tickets[jobSlot].partMask)); gone = live == 0u; }
                 if (gone) {
                     if (slotRole) ownJob = false; else { curSlot = kNoSlot; scanMask = true; }
-                } else curPart = (curPart + 1u) % parts;
+                } else {   // a partition that still has batches (one load: no ticket atomic is spent on an empty one)
+                    const uint32_t q = (waveId + partsTried) & 31u;   // (spread by the wave's own number: the waves that find a partition empty find it together)
+                    const uint32_t rotp = q ? ((live >> q) | (live << (32u - q))) : live;
+                    curPart = (static_cast<uint32_t>(__builtin_ctz(rotp)) + q) & 31u;
+                }
                 continue;
             }
-            // the LAST batch of a partition counts the partition down, the last partition clears the slot's bit: both by waves that hold
+            // the LAST batch of a partition clears the partition's bit, the last partition the slot's bit in the work mask: both by waves that hold
             // a valid batch, so the tile cannot complete (and the slot post another) before they are done
             if (batch + 1u == hi && lane == 0) {
-                if (__hip_atomic_fetch_sub(&st->tickets[jobSlot].partsLeft, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
+                const uint32_t others = ~(1u << curPart);
+                if ((__hip_atomic_fetch_and(&st->tickets[jobSlot].partMask, others, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & others) == 0u)
                     (void)__hip_atomic_fetch_and(workMask, ~(1ull << jobSlot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             jobSeq = gen;

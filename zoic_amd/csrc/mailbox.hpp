@@ -81,8 +81,9 @@ struct alignas(64) TileJob {                  // three 16-byte chunks, each endi
 struct alignas(64) TileCounter { unsigned long long next; uint32_t pad[14]; };   // (generation << 32) | next batch of the partition
 struct alignas(64) TileTickets {
     TileCounter part[kTileParts];             // one atomicAdd hands a batch out
-    uint32_t partsLeft, pad[15];              // partitions with batches left: the wave that draws a partition's last batch counts it down,
-};                                            // the one that counts the last partition clears the slot's bit in the work mask
+    uint32_t partMask, pad[15];               // bit p: partition p has batches left.  The wave that draws a partition's last batch clears its bit, the
+};                                            // one that clears the last bit clears the slot's bit in the work mask; a wave that finds its partition
+                                              // empty reads this word and goes straight to one that is not (up to 31 wasted ticket atomics before)
 struct alignas(64) TileWake { unsigned long long word; uint32_t pad[14]; };   // per WORKER wave: (changing number << 32) | exit << 16 | partition << 8 | slot (6 bits)
 struct MailDeviceState {
     uint32_t served[kMailSlots];              // sequence number of the last call each slot answered
