@@ -582,9 +582,12 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                     unsigned long long mask = first_lane64(load_dev(workMask));
                     bool found = false;
                     for (uint32_t tries = 0; mask != 0ull && tries < 4u && !found; ++tries) {
-                        const uint32_t r = waveId & 63u;   // every worker starts its search at another slot
-                        const unsigned long long rot = r ? ((mask >> r) | (mask << (64u - r))) : mask;
-                        const uint32_t cand = (static_cast<uint32_t>(__builtin_ctzll(rot)) + r) & 63u;
+                        // the k-th posted slot, k by the wave's own number: every posted tile gets its share of the waves that run dry
+                        // ("the first set bit at or behind waveId mod 64" sent three quarters of them to the lowest slot of sixteen)
+                        uint32_t k = (waveId + tries * 7u) % static_cast<uint32_t>(__builtin_popcountll(mask));
+                        unsigned long long mm = mask;
+                        for (; k != 0u; --k) mm &= mm - 1ull;
+                        const uint32_t cand = static_cast<uint32_t>(__builtin_ctzll(mm));
                         const uint32_t live = first_lane(load_dev(&st->tickets[cand].partMask));
                         if (live != 0u) {
                             const uint32_t q = (waveId >> 6) & 31u;
