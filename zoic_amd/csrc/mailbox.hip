@@ -533,6 +533,13 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                     const uint32_t batches = (jobN + jobRays - 1u) / jobRays;
                     uint32_t parts = batches / 8u;   // about eight batches per counter: same-address atomics queue up (~0.1 us each across the XCDs)
                     parts = parts < 1u ? 1u : (parts > kTileParts ? kTileParts : parts);
+                    // the first worker to wake: the next stretch of the wake lines, so that tiles of different render threads wake different
+                    // waves (the returning atomic is issued HERE and comes back behind the fence below: rounds 5's first versions waited for it
+                    // where the wake lines are written, ~1 us of every tile's hand-off; a stretch computed from the slot and the tile's number
+                    // instead cost nothing and made the tiles of four threads share their workers)
+                    const uint32_t wakeN = workerWaves == 0u ? 0u : (batches - 1u < workerWaves ? batches - 1u : workerWaves);
+                    uint32_t wakeAt = 0;
+                    if (lane == 0 && wakeN != 0u) wakeAt = __hip_atomic_fetch_add(control + 8, wakeN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0) {
                         uint4 *J = reinterpret_cast<uint4 *>(st->jobs + slot);
                         store_dev4(J, make_uint4(lane_word(line.x, 0), lane_word(line.y, 0), jobN, seq));
@@ -551,15 +558,11 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                     // (the descriptor is fenced in front of the counters: whoever draws a ticket of this generation MUST find it, or the
                     // ticket -- a batch -- is lost.  The counters and the bit are NOT fenced in front of the wake lines: a woken worker acts on
                     // them a poll and an atomic's round trip later, and one that still draws a stale ticket only goes back to sleep -- a lost
-                    // wake-up costs time, the slot's wave hands its tile's batches out itself in the end.  The fence here, and the returning atomic
-                    // that rotated the first worker to wake, cost every tile ~1.5 us of hand-off.)
+                    // wake-up costs time, the slot's wave hands its tile's batches out itself in the end.  The fence that used to stand here cost
+                    // every tile ~0.5 us of hand-off.)
                     if (lane == 0) (void)__hip_atomic_fetch_or(workMask, 1ull << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (workerWaves != 0u) {
-                        const uint32_t wakeN = batches - 1u < workerWaves ? batches - 1u : workerWaves;
-                        // the first worker to wake: another stretch of the wake lines per slot and per tile, so that tiles of different
-                        // render threads mostly wake different waves (two tiles on one worker: the later wake wins, the other tile's batch
-                        // is drawn by whoever runs dry first)
-                        const uint32_t at = (slot * 257u + seq * 61u) % workerWaves;
+                    if (wakeN != 0u) {
+                        const uint32_t at = first_lane(wakeAt);
                         const unsigned long long tag = (static_cast<unsigned long long>(static_cast<uint32_t>(now) | 1u) << 32) | slot;
                         // the i-th woken worker is meant for batch i + 1: it starts on that batch's partition (partition 0 is one batch
                         // short -- this wave's -- and every partition gets exactly as many workers as it has batches)

@@ -89,7 +89,7 @@ struct MailDeviceState {
     uint32_t served[kMailSlots];              // sequence number of the last call each slot answered
     alignas(64) uint32_t control[16];         // [0] exit flag, [1] waves that have left, [2..3] wall-clock time of the last call,
                                               // [4..5] 64-bit mask of the slots whose tile still has batches to hand out,
-                                              // ([8]: unused since the first worker to wake is computed from the slot and the tile's number)
+                                              // [8] next worker wave to wake (rotates: tiles of different slots wake different waves)
     TileJob jobs[kMailSlots];
     TileTickets tickets[kMailSlots];
     TileWake wake[kTileMaxWorkerWaves];
