@@ -41,7 +41,8 @@ extern "C" {
  *      to 50 ms for it to retire (zoic_camera_get_counters / _update / _destroy stop it first); the zoic_frame_* entry points
  *      (one frame over several devices of this process); zoic_lens_info gained precomputeTIR behind fastRunsStrict (8 bytes in all).
  *   4  round 5: zoic_tile_* / zoic_camera_create_rays_tile (bucket-sized batches through the resident kernel, no launch);
- *      zoic_frame_get_lane_info; ZOIC_FRAME_PAYLOAD_SPARSE; zoic_camera_set_frame_aspect.  Nothing of ABI 3 changed shape. */
+ *      zoic_frame_get_lane_info; ZOIC_FRAME_PAYLOAD_SPARSE; zoic_camera_set_frame_aspect; zoic_tile_set_rows / zoic_tile_rays.
+ *      Nothing of ABI 3 changed shape. */
 #define ZOIC_AMD_ABI_VERSION 4
 
 typedef enum zoic_status {
@@ -236,8 +237,15 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
  * be used from different threads at once.  zoic_camera_update / _destroy: wait for (or destroy) the camera's tiles first.
  * zoic_camera_create_rays_tile is the one-call form for arrays the caller owns: page-locked mapped arrays (zoic_host_alloc /
  * zoic_host_register) are used in place, anything else is staged through the slot's own page-locked buffers (two 16 Ki-row
- * pieces in flight).  Any n.  Counters: tile rays count like every other ray. */
+ * pieces in flight).  Any n.  Counters: tile rays count like every other ray.
+ *   zoic_tile_set_rows(tile, ZOIC_TILE_ROWS_RAYS)  the tile's answer is n zoic_ray RECORDS (32 bytes: origin, dir, weight, flags --
+ *                     what zoic_create_rays_device writes, bit for bit) at zoic_tile_rays() instead of n AtCameraOutput rows (84 bytes,
+ *                     51 of them zeros or copies): with many render threads a tile costs what its rows cost on PCIe, and a
+ *                     renderer that reads origin / dir / weight (dOdy = origin, dDdy = dir when flags bit 0 is set, zoic.cpp:1974-1977)
+ *                     needs nothing else.  ZOIC_TILE_ROWS_ARNOLD (the default) switches back.  Between a wait and the next submit only. */
 #define ZOIC_TILE_MAX_SAMPLES 65536u
+#define ZOIC_TILE_ROWS_ARNOLD 0
+#define ZOIC_TILE_ROWS_RAYS 1
 typedef struct zoic_tile zoic_tile;
 zoic_status zoic_tile_create(zoic_camera *cam, uint32_t capacity, uint16_t tid, zoic_tile **out);
 void        zoic_tile_destroy(zoic_tile *tile);
@@ -247,6 +255,8 @@ uint32_t    zoic_tile_capacity(const zoic_tile *tile);
 zoic_status zoic_tile_submit(zoic_tile *tile, uint32_t n, uint64_t ray_index_base);
 zoic_status zoic_tile_wait(zoic_tile *tile);
 int         zoic_tile_done(zoic_tile *tile);
+zoic_status zoic_tile_set_rows(zoic_tile *tile, int rows);
+const zoic_ray *zoic_tile_rays(const zoic_tile *tile);
 zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,
                                          uint64_t ray_index_base, uint16_t tid);
 /* camera_reverse_ray, zoic.cpp:1992-1995: the reference returns false and writes nothing; so does this (returns 0). */

@@ -73,6 +73,35 @@ def test_a_tile_equals_the_arnold_batch_call_bit_for_bit(gpu, cfg, where, precis
     cam.close()
 
 
+@pytest.mark.parametrize("cfg,where", [("C1", 0.4), ("C2", 0.08), ("C4", 0.5)])
+@pytest.mark.parametrize("precision", [PRECISION_STRICT, PRECISION_FAST])
+def test_a_tile_of_ray_records_equals_the_device_call_bit_for_bit(gpu, cfg, where, precision):
+    """zoic_tile_set_rows(ZOIC_TILE_ROWS_RAYS): the tile's answer is n 32-byte zoic_ray records -- origin, dir, weight, flags -- instead of
+    n 84-byte AtCameraOutput rows: the records zoic_create_rays_device writes for the same samples and ray indices, bit for bit; nothing
+    beyond record n is touched; switching back gives the Arnold rows again."""
+    import torch
+    cam = camera(cfg, precision)
+    a, s, base = inputs_of(cfg, 65536, where)
+    ref = cam.create_rays(torch.from_numpy(s).cuda(), ray_index_base=base)["rays"].cpu().numpy()
+    rows = cam.create_rays_arnold(a, ray_index_base=base)
+    tile = cam.tile(65536, tid=9)
+    tile.set_rows(1)
+    for n in (1, 63, 4096, 65536):
+        tile.rays[:] = np.float32(7.0)
+        tile.inputs[:n] = a[:n]
+        tile.submit(n, base)
+        tile.wait()
+        assert same_rows(tile.rays[:n], ref[:n]), (cfg, precision, n, np.nonzero((bits(tile.rays[:n]) != bits(ref[:n])).any(1))[0][:5])
+        assert (tile.rays[n:n + 8] == 7.0).all()
+    tile.set_rows(0)
+    tile.outputs[:] = np.float32(7.0)
+    tile.submit(4096, base)
+    tile.wait()
+    assert same_rows(tile.outputs[:4096], rows[:4096])
+    tile.close()
+    cam.close()
+
+
 @pytest.mark.parametrize("cfg,where", [("C2", 0.08), ("C3", 0.3), ("C5", 0.12), ("C1", 0.4)])
 def test_a_strict_tile_equals_the_oracle(gpu, oracle_lib, cfg, where):
     """No intermediary: STRICT tile rows against the oracle's rays (per-ray streams keyed by the global ray index), counters too."""

@@ -19,7 +19,7 @@
 #include "zoic_amd.h"
 
 static zoic_camera *cam;
-static int tiles = 200, mode = 0;
+static int tiles = 200, mode = 0, rows = 0;   /* rows: 1 = zoic_ray records instead of AtCameraOutput rows (mode 0 only) */
 static uint32_t per_tile = 65536;
 static double *lat;   /* threads x tiles */
 static pthread_barrier_t go;
@@ -79,6 +79,7 @@ static void *worker(void *arg)
     zoic_camera_output *out = NULL;
     if (mode == 0) {
         if (zoic_tile_create(cam, per_tile, (uint16_t)tid, &tile) != ZOIC_OK) { fprintf(stderr, "tile: %s\n", zoic_last_error_string()); exit(2); }
+        if (rows && zoic_tile_set_rows(tile, ZOIC_TILE_ROWS_RAYS) != ZOIC_OK) { fprintf(stderr, "tile rows: %s\n", zoic_last_error_string()); exit(2); }
         in = zoic_tile_inputs(tile); out = zoic_tile_outputs(tile);
     } else if (mode == 3) {
         if (zoic_host_alloc(sizeof(*in) * per_tile, (void **)&in) != ZOIC_OK || zoic_host_alloc(sizeof(*out) * per_tile, (void **)&out) != ZOIC_OK) exit(2);
@@ -101,7 +102,8 @@ static void *worker(void *arg)
         else st = zoic_create_rays_arnold(cam, per_tile, in, out, base);
         if (st != ZOIC_OK) { fprintf(stderr, "tile call: %s\n", zoic_last_error_string()); exit(2); }
         if (k >= 0) lat[(size_t)tid * tiles + k] = now_us() - t0;
-        sum += out[(size_t)(k + warm) % per_tile].dir.z + out[per_tile - 1].weight[0];
+        if (rows) { const zoic_ray *r = (const zoic_ray *)out; sum += r[(size_t)(k + warm) % per_tile].dz + r[per_tile - 1].weight; }
+        else sum += out[(size_t)(k + warm) % per_tile].dir.z + out[per_tile - 1].weight[0];
     }
     t_end[tid] = now_us();
     sums[tid] = sum;
@@ -113,12 +115,13 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: tile_latency lens.dat [threads] [samples_per_tile] [tiles_per_thread] [precision] [lensModel] [mode]\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: tile_latency lens.dat [threads] [samples_per_tile] [tiles_per_thread] [precision] [lensModel] [mode] [rows]\n"); return 1; }
     const int threads = argc > 2 ? atoi(argv[2]) : 16;
     if (argc > 3) per_tile = (uint32_t)atoi(argv[3]);
     if (argc > 4) tiles = atoi(argv[4]);
     const int precision = argc > 5 ? atoi(argv[5]) : ZOIC_PRECISION_FAST, model = argc > 6 ? atoi(argv[6]) : ZOIC_RAYTRACED;
     if (argc > 7) mode = atoi(argv[7]);
+    if (argc > 8) rows = atoi(argv[8]);
     if (threads < 1 || threads > 256 || per_tile < 4 || (mode <= 0 && per_tile > ZOIC_TILE_MAX_SAMPLES) || tiles < 1) { fprintf(stderr, "bad arguments\n"); return 1; }
     zoic_params p;
     zoic_params_default(&p);

@@ -2,7 +2,7 @@
 # tools/r5_tile_timing.sh [tag] -- where a tile batch's time goes: the -DZOIC_TILE_TIMING build (tools/ubench/timing/libzoic_amd.so, built by
 #   python -c "from zoic_amd import build as B; B.build(force=True, extra_flags=['-DZOIC_TILE_TIMING'], out='tools/ubench/timing/libzoic_amd.so', objdir='tools/ubench/obj_timing')")
 # prints its region histograms when the camera is destroyed
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out   # (mkdir -p tools/ubench/timing before building the library there)
 TAG=${1:-x}
 export LD_LIBRARY_PATH=$PWD/tools/ubench/timing:$LD_LIBRARY_PATH
 for L in double_gauss_f2.0 tessar_f2.8; do

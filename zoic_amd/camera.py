@@ -112,6 +112,12 @@ class ZoicTile:
         pout = C.cast(self._lib.zoic_tile_outputs(h), C.c_void_p).value
         self.inputs = np.frombuffer((C.c_char * (self.capacity * 28)).from_address(pin), dtype=np.float32).reshape(self.capacity, 7)
         self.outputs = np.frombuffer((C.c_char * (self.capacity * 84)).from_address(pout), dtype=np.float32).reshape(self.capacity, 21)
+        # the same memory as (capacity, 8) float32 zoic_ray records: what the kernel writes after set_rows(1)
+        self.rays = np.frombuffer((C.c_char * (self.capacity * 32)).from_address(pout), dtype=np.float32).reshape(self.capacity, 8)
+
+    def set_rows(self, rows):
+        """0: AtCameraOutput rows in `outputs` (the default); 1: zoic_ray records in `rays` (32 instead of 84 bytes a ray across PCIe)."""
+        self._cam._check(self._lib.zoic_tile_set_rows(self._h, int(rows)))
 
     def submit(self, n, ray_index_base=0):
         self._cam._check(self._lib.zoic_tile_submit(self._h, int(n), int(ray_index_base)))

@@ -328,6 +328,7 @@ struct zoic_tile {
     zoic_camera_output *outputs = nullptr;
     uint64_t dIn = 0, dOut = 0;       // the same arrays as the device sees them
     uint32_t seq = 0;                 // the submit not waited for yet (0: none); under the slot's mutex
+    int rows = ZOIC_TILE_ROWS_ARNOLD; // what the kernel writes at dOut: AtCameraOutput rows or zoic_ray records
 };
 
 void Mailbox::release()
@@ -1342,14 +1343,14 @@ static zoic_status tile_alloc(zoic_camera *cam, uint32_t capacity, uint16_t tid,
 }
 
 // post n rows at (dIn -> dOut) on `slot`; slotM[slot] is held and no tile is in flight on it
-static zoic_status tile_post_locked(zoic_camera *cam, unsigned slot, uint32_t n, uint64_t dIn, uint64_t dOut, uint64_t base, uint32_t *seqOut)
+static zoic_status tile_post_locked(zoic_camera *cam, unsigned slot, uint32_t n, uint64_t dIn, uint64_t dOut, uint64_t base, uint32_t *seqOut, int rows = ZOIC_TILE_ROWS_ARNOLD)
 {
     Mailbox &M = cam->mail;
     if (M.slotsInUse.load(std::memory_order_acquire) <= slot || M.workerGroups.load(std::memory_order_acquire) == 0u || M.header()->alive == 0u)
         if (zoic_status s = mailbox_ensure_running(cam, slot, true)) return s;
     const uint32_t seq = ++M.seq[slot];
     volatile MailTileRequest *q = reinterpret_cast<volatile MailTileRequest *>(M.request(slot));
-    q->baseHi = static_cast<uint32_t>(base >> 32); q->pad = 0u; q->kind = 1u;
+    q->baseHi = static_cast<uint32_t>(base >> 32); q->pad = static_cast<uint32_t>(rows); q->kind = 1u;
     q->outLo = static_cast<uint32_t>(dOut); q->outHi = static_cast<uint32_t>(dOut >> 32); q->baseLo = static_cast<uint32_t>(base);
     q->inLo = static_cast<uint32_t>(dIn); q->inHi = static_cast<uint32_t>(dIn >> 32); q->n = n;
     std::atomic_thread_fence(std::memory_order_release);   // the caller's input rows and the words above, then the numbers
@@ -1407,7 +1408,7 @@ zoic_status zoic_tile_submit(zoic_tile *tile, uint32_t n, uint64_t ray_index_bas
     // one request per slot at a time: this tile's previous submit, or another tile of the same slot (tids 64 apart), comes first
     if (cam->mail.mem.host) if (zoic_status s = tile_settle_locked(cam, tile->slot)) return s;
     tile->seq = 0u;
-    return tile_post_locked(cam, tile->slot, n, tile->dIn, tile->dOut, ray_index_base, &tile->seq);
+    return tile_post_locked(cam, tile->slot, n, tile->dIn, tile->dOut, ray_index_base, &tile->seq, tile->rows);
 }
 
 zoic_status zoic_tile_wait(zoic_tile *tile)
@@ -1423,6 +1424,17 @@ zoic_status zoic_tile_wait(zoic_tile *tile)
     tile->seq = 0u;
     return ZOIC_OK;
 }
+
+zoic_status zoic_tile_set_rows(zoic_tile *tile, int rows)
+{
+    if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
+    if (rows != ZOIC_TILE_ROWS_ARNOLD && rows != ZOIC_TILE_ROWS_RAYS) return fail(ZOIC_ERR_INVALID_ARGUMENT, "rows: ZOIC_TILE_ROWS_ARNOLD or ZOIC_TILE_ROWS_RAYS");
+    if (tile->seq != 0u) return fail(ZOIC_ERR_INVALID_ARGUMENT, "zoic_tile_set_rows between a submit and its wait");
+    tile->rows = rows;
+    return ZOIC_OK;
+}
+
+const zoic_ray *zoic_tile_rays(const zoic_tile *tile) { return tile ? reinterpret_cast<const zoic_ray *>(tile->outputs) : nullptr; }
 
 int zoic_tile_done(zoic_tile *tile)
 {

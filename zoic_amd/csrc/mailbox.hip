@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         uint32_t work = 0;      // 1: one sample (slot role), 2: one 64-sample batch of a tile
         float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         Rng rng{1u, 2u, 3u, 4u};
-        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobSeq = 0, jobRays = kRays;
+        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobSeq = 0, jobRays = kRays, jobRows = 0;
         unsigned long long jobIn = 0, jobOut = 0, jobBase = 0;
         if (slotRole && !ownJob) {
             u32x4 line, ctl;   // ctl: the launch's control block = {exit flag, waves out, time of the last call (lo, hi)}
@@ -522,6 +522,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 jobOut = (static_cast<unsigned long long>(lane_word(line.y, 1)) << 32) | lane_word(line.x, 1);
                 jobBase = (static_cast<unsigned long long>(lane_word(line.x, 2)) << 32) | lane_word(line.z, 1);
                 jobSeq = seq; jobSlot = slot; batch = 0;
+                jobRows = lane_word(line.y, 2) & 1u;   // what to write at `out`: AtCameraOutput rows / zoic_ray records (mailbox.hpp)
                 if (jobN == 0u) continue;       // (the host never posts an empty tile)
                 work = 2;                       // batch 0 is this wave's, straight from the request: a tile of one batch involves nobody else
                 jobRays = tile_rays_per_batch(MODEL == 0, jobN);
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                         uint4 *J = reinterpret_cast<uint4 *>(st->jobs + slot);
                         store_dev4(J, make_uint4(lane_word(line.x, 0), lane_word(line.y, 0), jobN, seq));
                         store_dev4(J + 1, make_uint4(lane_word(line.x, 1), lane_word(line.y, 1), lane_word(line.z, 1), seq));
-                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts | (jobRays << 16), seq));
+                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts | (jobRows << 8) | (jobRays << 16), seq));
                         {   // the partitions that hold a batch at all (ceil(batches / parts) per partition can leave the last ones empty)
                             const uint32_t per0 = (batches + parts - 1u) / parts, live = (batches + per0 - 1u) / per0;
                             store_dev(&st->tickets[slot].partMask, live >= 32u ? 0xffffffffu : ((1u << live) - 1u));
@@ -631,8 +632,8 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 load_dev4x3(J, c0, c1, c2);
             }
-            const uint32_t batches = first_lane(c2.y), parts = first_lane(c2.z) & 0xffffu;
-            jobRays = first_lane(c2.z) >> 16;
+            const uint32_t batches = first_lane(c2.y), parts = first_lane(c2.z) & 0xffu;
+            jobRays = first_lane(c2.z) >> 16; jobRows = (first_lane(c2.z) >> 8) & 1u;
             const bool sameTile = first_lane(c0.w) == gen && first_lane(c1.w) == gen && first_lane(c2.w) == gen;
             const uint32_t per = sameTile ? (batches + parts - 1u) / parts : 1u;
             const uint32_t lo = curPart * per, hi = lo + per < batches ? lo + per : batches;   // the partition's batches
@@ -750,7 +751,16 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         // AtCameraOutput rows (84 bytes = 21 floats: origin, dir, dOdx, dOdy, dDdx, dDdy, weight[3]) as zoic_create_rays_arnold
         // writes them (kernels.hip expand_outputs_kernel): origin / dir, dOdy = origin and dDdy = dir for retried rays
         // (zoic.cpp:1974-1977), weight r = g = b, zeros in what camera_create_ray leaves alone.  One lane per output FLOAT.
-        {
+        if (jobRows != 0u) {   // ZOIC_TILE_ROWS_RAYS: the records as they stand in the stage -- 32 bytes a ray instead of 84 across PCIe
+            uint32_t *dst = reinterpret_cast<uint32_t *>(jobOut) + static_cast<size_t>(first) * 8u;
+            const uint32_t total = cnt * 8u;
+#pragma unroll
+            for (uint32_t k = 0; k < (kRays * 8u + 63u) / 64u; ++k) {
+                const uint32_t j = k * 64u + lane;
+                if (j < total) store_sys(dst + j, __builtin_bit_cast(uint32_t, stage[j]));
+            }
+            wave_lds_fence();
+        } else {
             uint32_t *dst = reinterpret_cast<uint32_t *>(jobOut) + static_cast<size_t>(first) * 21u;
             const uint32_t total = cnt * 21u;
 #pragma unroll
