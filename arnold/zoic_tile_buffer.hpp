@@ -29,9 +29,16 @@
 
 class ZoicTileBuffer {
 public:
-    ZoicTileBuffer(zoic_camera *cam, uint32_t capacity, uint16_t tid) : tile_(nullptr), in_(nullptr), out_(nullptr), n_(0), flushed_(0)
+    // rayRecords: the bucket is answered with 32-byte zoic_ray records instead of 84-byte AtCameraOutput rows (zoic_tile_set_rows): what a
+    // bucket costs with many render threads is what crosses PCIe.  serve() is the same either way; row() needs the rows.
+    ZoicTileBuffer(zoic_camera *cam, uint32_t capacity, uint16_t tid, bool rayRecords = false)
+        : tile_(nullptr), in_(nullptr), out_(nullptr), rays_(nullptr), n_(0), flushed_(0)
     {
         if (zoic_tile_create(cam, capacity, tid, &tile_) != ZOIC_OK) throw std::runtime_error(std::string("zoic_tile_create: ") + zoic_last_error_string());
+        if (rayRecords) {
+            if (zoic_tile_set_rows(tile_, ZOIC_TILE_ROWS_RAYS) != ZOIC_OK) { zoic_tile_destroy(tile_); throw std::runtime_error(std::string("zoic_tile_set_rows: ") + zoic_last_error_string()); }
+            rays_ = zoic_tile_rays(tile_);
+        }
         in_ = zoic_tile_inputs(tile_);
         out_ = zoic_tile_outputs(tile_);
         capacity_ = zoic_tile_capacity(tile_);
@@ -65,12 +72,22 @@ public:
     bool done() { return zoic_tile_done(tile_) != 0; }
 
     // serve: the finished row as the library wrote it (a whole AtCameraOutput from a zero-initialised one with weight 1) ...
-    const zoic_camera_output &row(uint32_t i) const { return out_[i]; }
+    const zoic_camera_output &row(uint32_t i) const { if (rays_) throw std::logic_error("ZoicTileBuffer::row: this buffer holds zoic_ray records"); return out_[i]; }
+    const zoic_ray &ray(uint32_t i) const { if (!rays_) throw std::logic_error("ZoicTileBuffer::ray: this buffer holds AtCameraOutput rows"); return rays_[i]; }
     // ... or applied to the caller's AtCameraOutput exactly as camera_create_ray updates it in place (zoic.cpp:1960-1961 origin /
     // dir; 1825 / 1952 weight = 0; 1981-1987 weight *= exposure; 1974-1977 dOdy / dDdy for retried rays only; dOdx / dDdx and the
     // derivatives of first-try rays are left alone)
     void serve(uint32_t i, zoic_camera_output &output) const
     {
+        if (rays_) {   // the record says it all: flags bit 0 = retried (zoic_amd.h)
+            const zoic_ray &q = rays_[i];
+            output.origin.x = q.ox; output.origin.y = q.oy; output.origin.z = q.oz;
+            output.dir.x = q.dx; output.dir.y = q.dy; output.dir.z = q.dz;
+            if (q.weight == 0.0f) output.weight[0] = output.weight[1] = output.weight[2] = 0.0f;
+            else if (q.weight != 1.0f) { output.weight[0] *= q.weight; output.weight[1] *= q.weight; output.weight[2] *= q.weight; }
+            if (q.flags & 1u) { output.dOdy = output.origin; output.dDdy = output.dir; }
+            return;
+        }
         const zoic_camera_output &r = out_[i];
         output.origin = r.origin;
         output.dir = r.dir;
@@ -89,6 +106,7 @@ private:
     zoic_tile *tile_;
     zoic_camera_input *in_;
     zoic_camera_output *out_;
+    const zoic_ray *rays_;
     uint32_t capacity_, n_, flushed_;
 };
 

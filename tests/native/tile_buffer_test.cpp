@@ -1,7 +1,7 @@
 // tests/native/tile_buffer_test.cpp -- arnold/zoic_tile_buffer.hpp (accumulate -> flush -> serve) on a GPU box, from plain C++ against the
 // C-ABI: a bucket's rows equal zoic_create_rays_arnold's bit for bit, serve() updates a caller's AtCameraOutput the way
 // zoic_camera_create_ray does, several render threads with a buffer each.  Prints "tile_buffer_test OK" and exits 0.
-//   tile_buffer_test <lens.dat> [precision 0|1]
+//   tile_buffer_test <lens.dat> [precision 0|1] [ray records 0|1]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,12 +23,13 @@ int main(int argc, char **argv)
     p.lensDataPath = argv[1]; p.focalLength = 10.0f; p.fStop = 2.8f; p.exposureControl = 0.5f;
     check(zoic_camera_create(0, &cam) == ZOIC_OK && zoic_camera_update(cam, &p) == ZOIC_OK, "camera");
     check(zoic_camera_set_precision(cam, argc > 2 ? static_cast<zoic_precision>(std::atoi(argv[2])) : ZOIC_PRECISION_STRICT) == ZOIC_OK, "precision");
+    const bool rayRecords = argc > 3 && std::atoi(argv[3]) != 0;   // the buffers are answered with zoic_ray records (zoic_tile_set_rows)
     const uint32_t n = 64 * 64 * 4;
     const int threads = 6;
     std::vector<int> bad(threads, 0);
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t) th.emplace_back([&, t] {
-        ZoicTileBuffer tile(cam, n, static_cast<uint16_t>(t));
+        ZoicTileBuffer tile(cam, n, static_cast<uint16_t>(t), rayRecords);
         std::vector<zoic_camera_input> in(n);
         std::vector<zoic_camera_output> ref(n);
         uint32_t s = 99u + 31u * t;
@@ -46,7 +47,8 @@ int main(int argc, char **argv)
             if (zoic_create_rays_arnold(cam, n, in.data(), ref.data(), base) != ZOIC_OK) { bad[t] = 2; return; }
             uint32_t retried = 0, dead = 0;
             for (uint32_t i = 0; i < n; ++i) {
-                if (std::memcmp(&tile.row(i), &ref[i], sizeof(zoic_camera_output)) != 0) { bad[t] = 3; return; }
+                if (!rayRecords && std::memcmp(&tile.row(i), &ref[i], sizeof(zoic_camera_output)) != 0) { bad[t] = 3; return; }
+                if (rayRecords && (std::memcmp(&tile.ray(i).ox, &ref[i].origin, 12) != 0 || std::memcmp(&tile.ray(i).dx, &ref[i].dir, 12) != 0)) { bad[t] = 3; return; }
                 // serve(): what camera_create_ray does to the caller's output (weight 0.25 handed in, derivatives pre-set)
                 zoic_camera_output o;
                 std::memset(&o, 0, sizeof o);

@@ -269,10 +269,12 @@ def test_tile_argument_errors(gpu):
     cam.close()
 
 
+@pytest.mark.parametrize("rays", [0, 1])
 @pytest.mark.parametrize("precision", [0, 1])
-def test_the_cpp_tile_buffer_accumulate_flush_serve(gpu, precision):
+def test_the_cpp_tile_buffer_accumulate_flush_serve(gpu, precision, rays):
     """arnold/zoic_tile_buffer.hpp driven from plain C++ (tests/native/tile_buffer_test.cpp, built by __graft_entry__.build()): six
-    render threads with a ZoicTileBuffer each; rows == zoic_create_rays_arnold, serve() == camera_create_ray's in-place update."""
+    render threads with a ZoicTileBuffer each; rows == zoic_create_rays_arnold, serve() == camera_create_ray's in-place update -- with the
+    buffers answered in AtCameraOutput rows and in zoic_ray records."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -280,7 +282,7 @@ def test_the_cpp_tile_buffer_accumulate_flush_serve(gpu, precision):
     if not os.path.exists(exe):
         subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + os.path.join(root, "include"), exe + ".cpp", "-o", exe, "-L" + os.path.join(root, "zoic_amd"),
                                "-lzoic_amd", "-lpthread", "-Wl,-rpath," + os.path.join(root, "zoic_amd")])
-    out = subprocess.run([exe, os.path.join(root, "zoic_amd", "lenses", "tessar_f2.8.dat"), str(precision)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, os.path.join(root, "zoic_amd", "lenses", "tessar_f2.8.dat"), str(precision), str(rays)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "tile_buffer_test OK" in out.stdout, (out.stdout[-300:], out.stderr[-600:])
 
 
