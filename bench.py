@@ -522,7 +522,7 @@ def per_sample_latency():
 
 def tile_server_entry():
     """Bucket-sized calls through the resident tile server (zoic_tile_*, csrc/mailbox.hip) as render threads see them
-    (tools/native/tile_latency.c, built by __graft_entry__.build()): 16 threads x 64 x 64 x 16 spp tiles (AtCameraOutput rows, and zoic_ray records: zoic_tile_set_rows), 16 / 4 / 1 threads
+    (tools/native/tile_latency.c, built by __graft_entry__.build()): 16 threads x 64 x 64 x 16 spp tiles (AtCameraInput / AtCameraOutput rows, and 16-byte samples in / zoic_ray records out: zoic_tile_set_inputs / _set_rows), 16 / 4 / 1 threads
     with 4096-sample tiles, FAST, double Gauss at f/2 without the image; beside them the launch-based call they replace (zoic_create_rays_arnold on
     page-locked arrays) on the same shapes."""
     exe = os.path.join(ROOT, "tools", "native", "tile_latency")
@@ -530,7 +530,7 @@ def tile_server_entry():
     if not os.path.exists(exe):
         return {"error": "tools/native/tile_latency not built"}
     res = {}
-    legs = (("tile_16_threads_x_65536", ["16", "65536", "60", "1", "1", "0"]), ("tile_rays_16_threads_x_65536", ["16", "65536", "60", "1", "1", "0", "1"]),
+    legs = (("tile_16_threads_x_65536", ["16", "65536", "60", "1", "1", "0"]), ("tile_rays_16_threads_x_65536", ["16", "65536", "60", "1", "1", "0", "1", "1"]),
             ("tile_16_threads_x_4096", ["16", "4096", "600", "1", "1", "0"]),
             ("tile_4_threads_x_4096", ["4", "4096", "600", "1", "1", "0"]), ("tile_1_thread_x_4096", ["1", "4096", "1000", "1", "1", "0"]),
             ("tile_1_thread_x_256", ["1", "256", "1000", "1", "1", "0"]), ("tile_thin_lens_1_thread_x_4096", ["1", "4096", "1000", "1", "0", "0"]),

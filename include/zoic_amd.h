@@ -41,7 +41,7 @@ extern "C" {
  *      to 50 ms for it to retire (zoic_camera_get_counters / _update / _destroy stop it first); the zoic_frame_* entry points
  *      (one frame over several devices of this process); zoic_lens_info gained precomputeTIR behind fastRunsStrict (8 bytes in all).
  *   4  round 5: zoic_tile_* / zoic_camera_create_rays_tile (bucket-sized batches through the resident kernel, no launch);
- *      zoic_frame_get_lane_info; ZOIC_FRAME_PAYLOAD_SPARSE; zoic_camera_set_frame_aspect; zoic_tile_set_rows / zoic_tile_rays.
+ *      zoic_frame_get_lane_info; ZOIC_FRAME_PAYLOAD_SPARSE; zoic_camera_set_frame_aspect; zoic_tile_set_rows / zoic_tile_rays, zoic_tile_set_inputs / zoic_tile_samples.
  *      Nothing of ABI 3 changed shape. */
 #define ZOIC_AMD_ABI_VERSION 4
 
@@ -242,10 +242,15 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
  *                     what zoic_create_rays_device writes, bit for bit) at zoic_tile_rays() instead of n AtCameraOutput rows (84 bytes,
  *                     51 of them zeros or copies): with many render threads a tile costs what its rows cost on PCIe, and a
  *                     renderer that reads origin / dir / weight (dOdy = origin, dDdy = dir when flags bit 0 is set, zoic.cpp:1974-1977)
- *                     needs nothing else.  ZOIC_TILE_ROWS_ARNOLD (the default) switches back.  Between a wait and the next submit only. */
+ *                     needs nothing else.  ZOIC_TILE_ROWS_ARNOLD (the default) switches back.  Between a wait and the next submit only.
+ *   zoic_tile_set_inputs(tile, ZOIC_TILE_INPUTS_SAMPLES)  the tile is filled with 16-byte (sx, sy, lensx, lensy) samples at zoic_tile_samples()
+ *                     -- the four fields zoic reads (zoic.cpp:1853-1854, 1870), what zoic_create_rays_device takes -- instead of 28-byte
+ *                     AtCameraInput rows.  ZOIC_TILE_INPUTS_ARNOLD (the default) switches back.  Between a wait and the next submit only. */
 #define ZOIC_TILE_MAX_SAMPLES 65536u
 #define ZOIC_TILE_ROWS_ARNOLD 0
 #define ZOIC_TILE_ROWS_RAYS 1
+#define ZOIC_TILE_INPUTS_ARNOLD 0
+#define ZOIC_TILE_INPUTS_SAMPLES 1
 typedef struct zoic_tile zoic_tile;
 zoic_status zoic_tile_create(zoic_camera *cam, uint32_t capacity, uint16_t tid, zoic_tile **out);
 void        zoic_tile_destroy(zoic_tile *tile);
@@ -257,6 +262,8 @@ zoic_status zoic_tile_wait(zoic_tile *tile);
 int         zoic_tile_done(zoic_tile *tile);
 zoic_status zoic_tile_set_rows(zoic_tile *tile, int rows);
 const zoic_ray *zoic_tile_rays(const zoic_tile *tile);
+zoic_status zoic_tile_set_inputs(zoic_tile *tile, int inputs);
+float *zoic_tile_samples(zoic_tile *tile);   /* capacity x 4 floats: the same memory as zoic_tile_inputs */
 zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,
                                          uint64_t ray_index_base, uint16_t tid);
 /* camera_reverse_ray, zoic.cpp:1992-1995: the reference returns false and writes nothing; so does this (returns 0). */

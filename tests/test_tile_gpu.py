@@ -93,6 +93,16 @@ def test_a_tile_of_ray_records_equals_the_device_call_bit_for_bit(gpu, cfg, wher
         tile.wait()
         assert same_rows(tile.rays[:n], ref[:n]), (cfg, precision, n, np.nonzero((bits(tile.rays[:n]) != bits(ref[:n])).any(1))[0][:5])
         assert (tile.rays[n:n + 8] == 7.0).all()
+    # ... and filled with 16-byte samples instead of 28-byte AtCameraInput rows (zoic_tile_set_inputs): the same records
+    tile.set_inputs(1)
+    for n in (1, 65, 65536):
+        tile.rays[:] = np.float32(7.0)
+        tile.samples[:n] = s[:n]
+        tile.submit(n, base)
+        tile.wait()
+        assert same_rows(tile.rays[:n], ref[:n]), (cfg, precision, n)
+    tile.set_inputs(0)
+    tile.inputs[:4096] = a[:4096]
     tile.set_rows(0)
     tile.outputs[:] = np.float32(7.0)
     tile.submit(4096, base)

@@ -19,7 +19,8 @@
 #include "zoic_amd.h"
 
 static zoic_camera *cam;
-static int tiles = 200, mode = 0, rows = 0;   /* rows: 1 = zoic_ray records instead of AtCameraOutput rows (mode 0 only) */
+static int tiles = 200, mode = 0, rows = 0, ins = 0;   /* ins: 1 = 16-byte samples instead of AtCameraInput rows (mode 0 only) */
+/* rows: 1 = zoic_ray records instead of AtCameraOutput rows (mode 0 only) */
 static uint32_t per_tile = 65536;
 static double *lat;   /* threads x tiles */
 static pthread_barrier_t go;
@@ -56,16 +57,20 @@ static int pin_to_gpu_node(void)
 }
 
 /* a bucket of a 3840 x 2160 frame: consecutive pixels of a 64-pixel-wide block, every sample jittered */
-static void fill(zoic_camera_input *in, uint32_t n, uint32_t *state, int tid, int k)
+static void fill(zoic_camera_input *in0, size_t at, uint32_t n, uint32_t *state, int tid, int k)
 {
+    zoic_camera_input *in = in0 + at;
+    float *sm = (float *)in0 + 4 * at;   /* ins: the same memory as 16-byte samples */
     uint32_t s = *state;
     const float bx = (float)((tid * 7 + k * 13) % 60) / 60.0f * 1.9f - 0.95f, by = (float)((tid * 5 + k * 11) % 33) / 33.0f * 1.0f - 0.5f;
     for (uint32_t i = 0; i < n; ++i) {
-        s = s * 1664525u + 1013904223u; in[i].sx = bx + (float)(s >> 8) / 16777216.0f * (64.0f / 1920.0f);
-        s = s * 1664525u + 1013904223u; in[i].sy = by + (float)(s >> 8) / 16777216.0f * (64.0f / 1920.0f);
-        s = s * 1664525u + 1013904223u; in[i].lensx = (float)(s >> 8) / 16777216.0f;
-        s = s * 1664525u + 1013904223u; in[i].lensy = (float)(s >> 8) / 16777216.0f;
-        in[i].dsx = in[i].dsy = in[i].relative_time = 0.0f;
+        float sx, sy, lx, ly;
+        s = s * 1664525u + 1013904223u; sx = bx + (float)(s >> 8) / 16777216.0f * (64.0f / 1920.0f);
+        s = s * 1664525u + 1013904223u; sy = by + (float)(s >> 8) / 16777216.0f * (64.0f / 1920.0f);
+        s = s * 1664525u + 1013904223u; lx = (float)(s >> 8) / 16777216.0f;
+        s = s * 1664525u + 1013904223u; ly = (float)(s >> 8) / 16777216.0f;
+        if (ins) { sm[4 * i] = sx; sm[4 * i + 1] = sy; sm[4 * i + 2] = lx; sm[4 * i + 3] = ly; }
+        else { in[i].sx = sx; in[i].sy = sy; in[i].lensx = lx; in[i].lensy = ly; in[i].dsx = in[i].dsy = in[i].relative_time = 0.0f; }
     }
     *state = s;
 }
@@ -79,6 +84,7 @@ static void *worker(void *arg)
     zoic_camera_output *out = NULL;
     if (mode == 0) {
         if (zoic_tile_create(cam, per_tile, (uint16_t)tid, &tile) != ZOIC_OK) { fprintf(stderr, "tile: %s\n", zoic_last_error_string()); exit(2); }
+        if (ins && zoic_tile_set_inputs(tile, ZOIC_TILE_INPUTS_SAMPLES) != ZOIC_OK) { fprintf(stderr, "tile inputs: %s\n", zoic_last_error_string()); exit(2); }
         if (rows && zoic_tile_set_rows(tile, ZOIC_TILE_ROWS_RAYS) != ZOIC_OK) { fprintf(stderr, "tile rows: %s\n", zoic_last_error_string()); exit(2); }
         in = zoic_tile_inputs(tile); out = zoic_tile_outputs(tile);
     } else if (mode == 3) {
@@ -87,13 +93,13 @@ static void *worker(void *arg)
         in = malloc(sizeof(*in) * per_tile); out = malloc(sizeof(*out) * per_tile);
     }
     memset(out, 0, sizeof(*out) * per_tile);
-    fill(in, per_tile, &s, tid, 0);
+    fill(in, 0, per_tile, &s, tid, 0);
     double sum = 0.0;
     const int warm = tiles > 20 ? 10 : 2;
     for (int k = -warm; k < tiles; ++k) {
         if (k == 0) { pthread_barrier_wait(&go); t_start[tid] = now_us(); }
         /* a fresh quarter of the inputs per tile (a renderer writes all of them; the generator here is slower than the GPU) */
-        fill(in + (size_t)((k + warm) & 3) * (per_tile / 4), per_tile / 4, &s, tid, k);
+        fill(in, (size_t)((k + warm) & 3) * (per_tile / 4), per_tile / 4, &s, tid, k);
         const uint64_t base = ((uint64_t)tid << 40) + (uint64_t)(k + warm) * per_tile;
         const double t0 = now_us();
         zoic_status st;
@@ -115,13 +121,14 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: tile_latency lens.dat [threads] [samples_per_tile] [tiles_per_thread] [precision] [lensModel] [mode] [rows]\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: tile_latency lens.dat [threads] [samples_per_tile] [tiles_per_thread] [precision] [lensModel] [mode] [rows] [ins]\n"); return 1; }
     const int threads = argc > 2 ? atoi(argv[2]) : 16;
     if (argc > 3) per_tile = (uint32_t)atoi(argv[3]);
     if (argc > 4) tiles = atoi(argv[4]);
     const int precision = argc > 5 ? atoi(argv[5]) : ZOIC_PRECISION_FAST, model = argc > 6 ? atoi(argv[6]) : ZOIC_RAYTRACED;
     if (argc > 7) mode = atoi(argv[7]);
     if (argc > 8) rows = atoi(argv[8]);
+    if (argc > 9) ins = atoi(argv[9]);
     if (threads < 1 || threads > 256 || per_tile < 4 || (mode <= 0 && per_tile > ZOIC_TILE_MAX_SAMPLES) || tiles < 1) { fprintf(stderr, "bad arguments\n"); return 1; }
     zoic_params p;
     zoic_params_default(&p);

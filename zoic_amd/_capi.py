@@ -103,6 +103,8 @@ SYMBOLS = {
     "zoic_tile_done": (C.c_int, [_vp]),
     "zoic_tile_set_rows": (C.c_int, [_vp, C.c_int]),
     "zoic_tile_rays": (C.c_void_p, [_vp]),
+    "zoic_tile_set_inputs": (C.c_int, [_vp, C.c_int]),
+    "zoic_tile_samples": (C.c_void_p, [_vp]),
     "zoic_camera_create_rays_tile": (C.c_int, [_vp, _u32, C.POINTER(CameraInput), C.POINTER(CameraOutput), _u64, C.c_uint16]),
     "zoic_camera_reverse_ray": (C.c_int, [_vp, C.POINTER(Vec3), C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "zoic_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),

@@ -112,12 +112,18 @@ class ZoicTile:
         pout = C.cast(self._lib.zoic_tile_outputs(h), C.c_void_p).value
         self.inputs = np.frombuffer((C.c_char * (self.capacity * 28)).from_address(pin), dtype=np.float32).reshape(self.capacity, 7)
         self.outputs = np.frombuffer((C.c_char * (self.capacity * 84)).from_address(pout), dtype=np.float32).reshape(self.capacity, 21)
+        # the same memory as (capacity, 4) float32 samples (sx, sy, lensx, lensy): what the kernel reads after set_inputs(1)
+        self.samples = np.frombuffer((C.c_char * (self.capacity * 16)).from_address(pin), dtype=np.float32).reshape(self.capacity, 4)
         # the same memory as (capacity, 8) float32 zoic_ray records: what the kernel writes after set_rows(1)
         self.rays = np.frombuffer((C.c_char * (self.capacity * 32)).from_address(pout), dtype=np.float32).reshape(self.capacity, 8)
 
     def set_rows(self, rows):
         """0: AtCameraOutput rows in `outputs` (the default); 1: zoic_ray records in `rays` (32 instead of 84 bytes a ray across PCIe)."""
         self._cam._check(self._lib.zoic_tile_set_rows(self._h, int(rows)))
+
+    def set_inputs(self, inputs):
+        """0: AtCameraInput rows in `inputs` (the default); 1: (sx, sy, lensx, lensy) in `samples` (16 instead of 28 bytes a sample)."""
+        self._cam._check(self._lib.zoic_tile_set_inputs(self._h, int(inputs)))
 
     def submit(self, n, ray_index_base=0):
         self._cam._check(self._lib.zoic_tile_submit(self._h, int(n), int(ray_index_base)))

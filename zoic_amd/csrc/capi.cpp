@@ -329,6 +329,7 @@ struct zoic_tile {
     uint64_t dIn = 0, dOut = 0;       // the same arrays as the device sees them
     uint32_t seq = 0;                 // the submit not waited for yet (0: none); under the slot's mutex
     int rows = ZOIC_TILE_ROWS_ARNOLD; // what the kernel writes at dOut: AtCameraOutput rows or zoic_ray records
+    int ins = ZOIC_TILE_INPUTS_ARNOLD; // what the caller writes at dIn: AtCameraInput rows or (sx, sy, lensx, lensy) samples
 };
 
 void Mailbox::release()
@@ -1408,7 +1409,7 @@ zoic_status zoic_tile_submit(zoic_tile *tile, uint32_t n, uint64_t ray_index_bas
     // one request per slot at a time: this tile's previous submit, or another tile of the same slot (tids 64 apart), comes first
     if (cam->mail.mem.host) if (zoic_status s = tile_settle_locked(cam, tile->slot)) return s;
     tile->seq = 0u;
-    return tile_post_locked(cam, tile->slot, n, tile->dIn, tile->dOut, ray_index_base, &tile->seq, tile->rows);
+    return tile_post_locked(cam, tile->slot, n, tile->dIn, tile->dOut, ray_index_base, &tile->seq, tile->rows | (tile->ins << 1));
 }
 
 zoic_status zoic_tile_wait(zoic_tile *tile)
@@ -1435,6 +1436,17 @@ zoic_status zoic_tile_set_rows(zoic_tile *tile, int rows)
 }
 
 const zoic_ray *zoic_tile_rays(const zoic_tile *tile) { return tile ? reinterpret_cast<const zoic_ray *>(tile->outputs) : nullptr; }
+
+zoic_status zoic_tile_set_inputs(zoic_tile *tile, int inputs)
+{
+    if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
+    if (inputs != ZOIC_TILE_INPUTS_ARNOLD && inputs != ZOIC_TILE_INPUTS_SAMPLES) return fail(ZOIC_ERR_INVALID_ARGUMENT, "inputs: ZOIC_TILE_INPUTS_ARNOLD or ZOIC_TILE_INPUTS_SAMPLES");
+    if (tile->seq != 0u) return fail(ZOIC_ERR_INVALID_ARGUMENT, "zoic_tile_set_inputs between a submit and its wait");
+    tile->ins = inputs;
+    return ZOIC_OK;
+}
+
+float *zoic_tile_samples(zoic_tile *tile) { return tile ? reinterpret_cast<float *>(tile->inputs) : nullptr; }
 
 int zoic_tile_done(zoic_tile *tile)
 {

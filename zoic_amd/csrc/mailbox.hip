@@ -414,6 +414,13 @@ __device__ __forceinline__ void store_dev4(uint4 *p, uint4 q)
     const u32x4 v = {q.x, q.y, q.z, q.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
+// 16 bytes of mapped host memory in one instruction, system scope (never from a GPU cache)
+__device__ __forceinline__ uint4 load_sys4(const uint4 *p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ uint32_t first_lane(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 __device__ __forceinline__ unsigned long long first_lane64(unsigned long long v)
 {
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         uint32_t work = 0;      // 1: one sample (slot role), 2: one 64-sample batch of a tile
         float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         Rng rng{1u, 2u, 3u, 4u};
-        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobSeq = 0, jobRays = kRays, jobRows = 0;
+        uint32_t seq = 0, jobSlot = 0, batch = 0, jobN = 0, jobSeq = 0, jobRays = kRays, jobRows = 0, jobIns = 0;
         unsigned long long jobIn = 0, jobOut = 0, jobBase = 0;
         if (slotRole && !ownJob) {
             u32x4 line, ctl;   // ctl: the launch's control block = {exit flag, waves out, time of the last call (lo, hi)}
@@ -523,6 +530,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 jobBase = (static_cast<unsigned long long>(lane_word(line.x, 2)) << 32) | lane_word(line.z, 1);
                 jobSeq = seq; jobSlot = slot; batch = 0;
                 jobRows = lane_word(line.y, 2) & 1u;   // what to write at `out`: AtCameraOutput rows / zoic_ray records (mailbox.hpp)
+                jobIns = (lane_word(line.y, 2) >> 1) & 1u;   // what stands at `in`: AtCameraInput rows / (sx, sy, lensx, lensy) samples
                 if (jobN == 0u) continue;       // (the host never posts an empty tile)
                 work = 2;                       // batch 0 is this wave's, straight from the request: a tile of one batch involves nobody else
                 jobRays = tile_rays_per_batch(MODEL == 0, jobN);
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                         uint4 *J = reinterpret_cast<uint4 *>(st->jobs + slot);
                         store_dev4(J, make_uint4(lane_word(line.x, 0), lane_word(line.y, 0), jobN, seq));
                         store_dev4(J + 1, make_uint4(lane_word(line.x, 1), lane_word(line.y, 1), lane_word(line.z, 1), seq));
-                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts | (jobRows << 8) | (jobRays << 16), seq));
+                        store_dev4(J + 2, make_uint4(lane_word(line.x, 2), batches, parts | (jobRows << 8) | (jobIns << 9) | (jobRays << 16), seq));
                         {   // the partitions that hold a batch at all (ceil(batches / parts) per partition can leave the last ones empty)
                             const uint32_t per0 = (batches + parts - 1u) / parts, live = (batches + per0 - 1u) / per0;
                             store_dev(&st->tickets[slot].partMask, live >= 32u ? 0xffffffffu : ((1u << live) - 1u));
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
                 load_dev4x3(J, c0, c1, c2);
             }
             const uint32_t batches = first_lane(c2.y), parts = first_lane(c2.z) & 0xffu;
-            jobRays = first_lane(c2.z) >> 16; jobRows = (first_lane(c2.z) >> 8) & 1u;
+            jobRays = first_lane(c2.z) >> 16; jobRows = (first_lane(c2.z) >> 8) & 1u; jobIns = (first_lane(c2.z) >> 9) & 1u;
             const bool sameTile = first_lane(c0.w) == gen && first_lane(c1.w) == gen && first_lane(c2.w) == gen;
             const uint32_t per = sameTile ? (batches + parts - 1u) / parts : 1u;
             const uint32_t lo = curPart * per, hi = lo + per < batches ? lo + per : batches;   // the partition's batches
@@ -684,6 +692,11 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
         if (work == 2u) {
             first = batch * jobRays;
             cnt = jobN - first < jobRays ? jobN - first : jobRays;
+            if (jobIns != 0u) {   // ZOIC_TILE_INPUTS_SAMPLES: 16 bytes a sample, the lane's own -- one instruction, no transpose
+                active = lane < cnt;
+                const uint4 q = load_sys4(reinterpret_cast<const uint4 *>(jobIn) + first + (active ? lane : 0u));
+                s = make_float4(__builtin_bit_cast(float, q.x), __builtin_bit_cast(float, q.y), __builtin_bit_cast(float, q.z), __builtin_bit_cast(float, q.w));
+            } else {
             // AtCameraInput rows are 7 dwords (sx sy dsx dsy lensx lensy relative_time): lane l fetches dword k * 64 + l of the batch's
             // 7 * cnt -- whole 256-byte runs per instruction across PCIe -- and picks its row out of LDS
             const uint32_t *src = reinterpret_cast<const uint32_t *>(jobIn) + static_cast<size_t>(first) * 7u;
@@ -699,6 +712,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             const uint32_t row = kIn + (active ? lane : 0u) * 7u;
             s = make_float4(stage[row], stage[row + 1u], stage[row + 4u], stage[row + 5u]);
             wave_lds_fence();   // ... before the records go into the same words
+            }
             rayBase = jobBase + first;
         }
 

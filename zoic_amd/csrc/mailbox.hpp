@@ -30,7 +30,7 @@ struct alignas(64) MailRequest {              // the number is the LAST word of 
 struct alignas(64) MailTileRequest {
     uint32_t inLo, inHi, n, seq0;
     uint32_t outLo, outHi, baseLo, seq1;
-    uint32_t baseHi, pad, kind, seq2;         // pad: what to write at `out` -- 0 AtCameraOutput rows (84 B), 1 zoic_ray records (32 B)
+    uint32_t baseHi, pad, kind, seq2;         // pad: bit 0 what to write at `out` -- AtCameraOutput rows (84 B) / zoic_ray records (32 B); bit 1 what stands at `in` -- AtCameraInput rows (28 B) / samples (16 B)
     uint32_t stop, fill[3];
 };
 struct alignas(64) MailReply {                // the number is the LAST word of a reply chunk: whatever order a chunk's bytes land in
@@ -75,7 +75,7 @@ constexpr uint32_t kTileMaxWorkerWaves = 1024;   // wake lines (kTileWorkerGroup
 struct alignas(64) TileJob {                  // three 16-byte chunks, each ending in the tile's sequence number (like a request line):
     uint32_t inLo, inHi, n, seq0;             // written by the slot's wave, read -- in the same round trip as the ticket -- by whoever
     uint32_t outLo, outHi, baseLo, seq1;      // draws one; a descriptor whose three numbers equal the ticket's generation is that tile's
-    uint32_t baseHi, batches, parts, seq2;    // parts: ticket partitions in use (1 ... kTileParts) | rows (0 / 1) << 8 | samples per batch << 16; partition p hands out batches
+    uint32_t baseHi, batches, parts, seq2;    // parts: ticket partitions in use (1 ... kTileParts) | rows (0 / 1) << 8 | inputs (0 / 1) << 9 | samples per batch << 16; partition p hands out batches
     uint32_t fill[4];                         //        [p * per, min((p + 1) * per, batches)), per = ceil(batches / parts)
 };
 struct alignas(64) TileCounter { unsigned long long next; uint32_t pad[14]; };   // (generation << 32) | next batch of the partition
