@@ -45,9 +45,10 @@ CPU_SLAB_RAYS = 16_588_800       # the fixed slab (= config 2's ful
 
 NOTES = {
     "roofline": "two candidate bounds (SURVEY 8d): HBM at 44 B/ray (16 B sample + 28 B origin/dir/weight) and FP32 VALU at the FLOP/ray the "
-                "oracle counts (profiles/flop_model_r04.json: 106 x interface visits + 130 x tries) against 157 TFLOP/s; bound = the lower "
-                "ceiling in rays/s (ceilings_grays), achieved / peak / frac = binding_frac are ITS figures, the other bound's are hbm_gb_s / "
-                "hbm_frac / flop_frac; kernel_ms = the launch (main kernel + the listed kernel over its work list) by HIP events on the "
+                "oracle counts for the work the kernels cannot avoid (profiles/flop_model_r06.json `executed`: 106 x interface visits + 130 x tries, "
+                "minus the tries proved away for dead pixels and retry-dead rays; flop_per_ray_as_written = the reference's loop as SURVEY prices it) "
+                "against 157 TFLOP/s; bound = the lower ceiling in rays/s (ceilings_grays), achieved / peak / frac = binding_frac are ITS figures "
+                "(<= 1 by construction), the other bound's are hbm_gb_s / hbm_frac / flop_frac; kernel_ms = the launch (main kernel + the listed kernel over its work list) by HIP events on the "
                 "launch stream; frac48 = HBM fraction with the 32 B record the kernels really write; traffic, lane_instr, lane_util = the "
                 "committed rocprofv3 PMC run of this (config, mode), profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE) -- null when "
                 "the kernel sources have changed since (csrc_sha16); valu_frac = wave64 VALU instr/s over 1024 SIMDs x 2.4 GHz / 2",
@@ -244,23 +245,32 @@ def pmc_entry(cfg_name, precision):
 
 
 def flop_per_ray(cfg_name):
-    """Algorithmic FLOP per ray: re-measured with the oracle's counters (tools/flop_model.py -> profiles/flop_model_r04.json),
-    SURVEY 8(d)'s probe figures when that file is missing."""
-    try:
-        return float(json.load(open(os.path.join(ROOT, "profiles", "flop_model_r04.json")))[cfg_name]["flop_per_ray"])
-    except Exception:
-        return {"C2": 1500.0, "C3": 1700.0, "C4": 1550.0, "C5": 3900.0}.get(cfg_name)
+    """(as written, executed) algorithmic FLOP per ray, measured with the oracle's counters (tools/flop_model.py -> profiles/flop_model_r06.json):
+    `as written` = every interface visit and try of the reference's loop (SURVEY 8d's model); `executed` = the same minus the tries the
+    kernels PROVE away instead of running (dead pixels: 27 identical tries are one; retry-dead rays: 26 retries that die at interface 0,
+    DESIGN 4.2).  The VALU bound is priced with `executed`: with `as written` a kernel that skips four fifths of C5's tries showed 245 % of
+    the FP32 peak -- a fraction above 1 is a wrong model, not a fast machine.  SURVEY 8(d)'s probe figures when the file is missing."""
+    for name in ("flop_model_r06.json", "flop_model_r04.json"):
+        try:
+            e = json.load(open(os.path.join(ROOT, "profiles", name)))[cfg_name]
+            return float(e["flop_per_ray"]), float(e.get("executed_flop_per_ray", e["flop_per_ray"]))
+        except Exception:
+            continue
+    f = {"C2": 1500.0, "C3": 1700.0, "C4": 1550.0, "C5": 3900.0}.get(cfg_name)
+    return f, f
 
 
 def roofline_block(cfg_name, precision, n, kernel_ms, thin):
-    """two candidate bounds -- HBM at 44 B/ray and FP32 VALU at the oracle-counted FLOP/ray -- both reported, and the
-    block's achieved / peak / frac are those of the BINDING one (the lower ceiling in rays/s): the thin lens is bound by HBM, the
-    Kolb configs by VALU.  binding_frac == frac; the other bound's figures sit beside it (hbm_* / flop_*)."""
+    """two candidate bounds -- HBM at 44 B/ray and FP32 VALU at the oracle-counted FLOP/ray the kernels cannot avoid (`executed`,
+    flop_per_ray above) -- both reported, and the block's achieved / peak / frac are those of the BINDING one (the lower ceiling in rays/s):
+    the thin lens and C5 (four fifths of its rays are dead pixels the kernels settle in one try) are bound by HBM, C2-C4 by VALU.
+    binding_frac == frac <= 1 by construction of both models; the other bound's figures sit beside it (hbm_* / flop_*), and the
+    reference's as-written FLOP count (`flop_per_ray_as_written`, what round 5 priced) for comparison."""
     secs = kernel_ms * 1e-3
     hbm_gbs = ALGO_BYTES_PER_RAY * n / secs / 1e9
     hbm_frac = hbm_gbs / HBM_PEAK_GBS
     ent = pmc_entry(cfg_name, precision)
-    fl = None if thin else flop_per_ray(cfg_name)
+    fl_written, fl = (None, None) if thin else flop_per_ray(cfg_name)
     tf = fl * n / secs / 1e12 if fl else None
     flop_frac = tf / FP32_PEAK_TFLOPS if tf else None
     ceil_hbm = HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_RAY / 1e9                      # Grays/s
@@ -277,13 +287,19 @@ def roofline_block(cfg_name, precision, n, kernel_ms, thin):
                 kernel="thin_rays_kernel" if thin else {"fast": "kolb_pool_guard_kernel + kolb_listed_kernel", "unchecked": "kolb_pool_fast_kernel",
                                                         "strict": "kolb_pool_strict_kernel"}[precision])
     if fl:
-        roof.update(flop_per_ray=round(fl), tflops=round(tf, 1), flop_frac=round(flop_frac, 3))
+        roof.update(flop_per_ray=round(fl), flop_model="executed (oracle-counted visits and tries minus the tries the kernels prove away: profiles/flop_model_r06.json)",
+                    tflops=round(tf, 1), flop_frac=round(flop_frac, 3), flop_per_ray_as_written=round(fl_written))
     if ent and ent.get("lane_instr_per_ray") and not thin:
         rate = ent["lane_instr_per_ray"] / 64.0 * n / secs / 1e12
         roof.update(lane_instr=round(ent["lane_instr_per_ray"]), lane_util=round(ent.get("valu_thread_util", 0.0), 3),
                     valu_frac=round(rate / VALU_PEAK_ARCH_TWIPS, 3))
-    if ent is None:
+        if ent.get("trans_per_ray") == ent.get("trans_per_ray") and ent.get("trans_per_ray") is not None:   # not NaN
+            roof["trans_per_ray"] = round(ent["trans_per_ray"], 1)
+    if ent:
+        roof["pmc_source"] = "committed rocprofv3 PMC run of these kernel sources on the profile box (profiles/pmc_traffic.json, csrc_sha16-guarded): traffic, lane_instr, lane_util"
+    else:
         roof["pmc"] = "no committed PMC run of these kernel sources (csrc_sha16 %s)" % csrc_sha16()
+    assert roof["frac"] <= 1.0 + 1e-9, "a roofline fraction above 1 means the model is wrong: %r" % (roof,)
     return roof
 
 
@@ -422,6 +438,9 @@ def sharded_frame_entry(torch, dist, cfg_name, dev, rank, world, local_rank, ste
             s = cam.generate_samples(b - a, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=a)
             mine = cam.create_rays(s, ray_index_base=a)["rays"][:, :PAYLOAD_FLOATS]
             ent["bit_identical_to_single_gpu"] = bool(torch.equal(mine.contiguous().view(torch.int32), full[a:b].view(torch.int32)))
+            # what ShardedFrame(sparse="auto") / ZOIC_FRAME_PAYLOAD_AUTO would pick for this camera (sparse iff >= 25 % of the frame's rays have weight 0)
+            zero = float((full[:, 6] == 0).to(torch.float64).mean())
+            ent.update(zero_weight_fraction=round(zero, 4), auto_layout="sparse" if zero >= ShardedFrame.AUTO_SPARSE_ZERO_WEIGHT else "dense")
         # LAST (everything above is safe if this leg misbehaves on its first meeting with real peers):
         # the gather with only the rays of weight != 0 on the wire (ShardedFrame(sparse=True): counts first, then bits + rows)
         try:
@@ -497,6 +516,48 @@ def single_process_frame_entry(torch, cfg_name, precision, devices, steps, warmu
         t_sparse = timed(lambda: frame.render(n, out=out, layout=FRAME_PAYLOAD_SPARSE))
         ent.update(with_sparse_gather=round(n * steps / t_sparse / 1e6, 1), sparse_gather_ms=round(t_sparse / steps * 1e3, 3),
                    root_bytes_sparse=sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices))))
+    frame.close()
+    del out
+    torch.cuda.empty_cache()
+    return ent
+
+
+def frame_layout_entry(torch, cfg_name, precision, devices, steps=3):
+    """what ZOIC_FRAME_PAYLOAD_AUTO picks for a camera, and what the two gather layouts move and cost there -- on an eighth of
+    the config's frame taken from its middle rows (the whole C5 frame is 59 GB of payload).  With one GPU listed twice this is bytes and a
+    code path, not a link measurement."""
+    from zoic_amd import FRAME_PAYLOAD, FRAME_PAYLOAD_AUTO, FRAME_PAYLOAD_SPARSE, PRECISION_FAST, PRECISION_FAST_UNCHECKED, PRECISION_STRICT, ZoicFrame
+    from zoic_amd.workloads import CONFIGS, camera_params, hexagon_bokeh, ray_count
+    cfg = CONFIGS[cfg_name]
+    n = ray_count(cfg_name) // 8 // 256 * 256
+    base = ray_count(cfg_name) * 7 // 16 // 256 * 256
+    ent = dict(config=cfg_name, rays=n, ray_index_base=base, devices=len(devices))
+    frame = ZoicFrame(devices)
+    if cfg["bokeh"]:
+        frame.set_bokeh_image(hexagon_bokeh())
+    frame.update(**camera_params(cfg_name))
+    frame.set_precision({"fast": PRECISION_FAST, "unchecked": PRECISION_FAST_UNCHECKED, "strict": PRECISION_STRICT}[precision])
+    frame.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=base)
+    root = torch.device("cuda", devices[0])
+    out = torch.empty((n, 7), dtype=torch.float32, device=root)
+    with torch.cuda.device(root):
+        for name, layout in (("dense", FRAME_PAYLOAD), ("sparse", FRAME_PAYLOAD_SPARSE)):
+            frame.render(n, ray_index_base=base, out=out, layout=layout)
+            torch.cuda.synchronize(root); frame.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                frame.render(n, ray_index_base=base, out=out, layout=layout)
+            torch.cuda.synchronize(root); frame.synchronize()
+            t = time.perf_counter() - t0
+            ent[name] = dict(mrays_s=round(n * steps / t / 1e6, 1), ms=round(t / steps * 1e3, 3),
+                             root_bytes=sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices))))
+        frame.update(**camera_params(cfg_name))     # AUTO decides per update: start it from scratch
+        for _ in range(2):
+            frame.render(n, ray_index_base=base, out=out, layout=FRAME_PAYLOAD_AUTO)
+            torch.cuda.synchronize(root)
+        layout, zero = frame.auto_layout()
+        ent.update(auto_picks={FRAME_PAYLOAD: "dense", FRAME_PAYLOAD_SPARSE: "sparse", None: "undecided"}[layout], zero_weight_fraction=round(zero, 4) if zero is not None else None,
+                   rule="sparse iff >= 25 % of the rays rendered since the update had weight 0")
     frame.close()
     del out
     torch.cuda.empty_cache()
@@ -817,6 +878,10 @@ def main():
                                      note="zoic_frame_* with the one GPU listed twice: code path + bit-identity on hardware, not a scaling number")
         except Exception as e:  # noqa: BLE001
             line["frame_api"] = {"failed": str(e)[:200]}
+        try:   # which gather layout the frame picks by itself (ZOIC_FRAME_PAYLOAD_AUTO), and what each moves: the headline camera and C5
+            line["frame_layout"] = [frame_layout_entry(torch, c, args.precision, [local_rank, local_rank]) for c in (args.config, "C5") ]
+        except Exception as e:  # noqa: BLE001
+            line["frame_layout"] = {"failed": str(e)[:200]}
     if not args.no_sharded:
         # north_star configs 4/5 on one GPU: nothing to gather, a slab is ONE launch (= the unsharded rates)
         line["sharded_frame"] = [sharded_frame_entry(torch, None, cname, dev, 0, 1, local_rank, st, args.gather_chunk_mb) for cname, st in (("C4", 5), ("C5", 2))]

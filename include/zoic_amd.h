@@ -42,8 +42,12 @@ extern "C" {
  *      (one frame over several devices of this process); zoic_lens_info gained precomputeTIR behind fastRunsStrict (8 bytes in all).
  *   4  round 5: zoic_tile_* / zoic_camera_create_rays_tile (bucket-sized batches through the resident kernel, no launch);
  *      zoic_frame_get_lane_info; ZOIC_FRAME_PAYLOAD_SPARSE; zoic_camera_set_frame_aspect; zoic_tile_set_rows / zoic_tile_rays, zoic_tile_set_inputs / zoic_tile_samples.
- *      Nothing of ABI 3 changed shape. */
-#define ZOIC_AMD_ABI_VERSION 4
+ *      Nothing of ABI 3 changed shape.
+ *   5  round 6: zoic_camera_set_wait_mode (how a render thread waits for the resident kernel: spin / yield / sleep); a zoic_tile that
+ *      outlives its camera is DETACHED by zoic_camera_destroy (every call but zoic_tile_destroy fails, the array getters return NULL)
+ *      instead of dangling; zoic_tile_done restarts a resident kernel that retired under the poll; ZOIC_FRAME_PAYLOAD_AUTO +
+ *      zoic_frame_auto_layout (the gather's layout chosen from the camera's dead-ray fraction).  Nothing of ABI 4 changed shape. */
+#define ZOIC_AMD_ABI_VERSION 5
 
 typedef enum zoic_status {
     ZOIC_OK = 0,
@@ -180,6 +184,16 @@ zoic_status zoic_camera_set_precision(zoic_camera *cam, zoic_precision mode);
  * 3:2 frame is inside it); a portrait frame passes its own 1/aspect > 1.  Takes effect at the next update that rebuilds tables
  * (or at once for the verdict of the next update when the value changed). */
 zoic_status zoic_camera_set_frame_aspect(zoic_camera *cam, float max_abs_sy);
+/* How a render thread waits for the camera's RESIDENT kernel (zoic_camera_create_ray, zoic_tile_wait, zoic_camera_create_rays_tile).
+ *   ZOIC_WAIT_SPIN   (default) a `pause` loop on the reply / the tile's flags: lowest latency, one core per waiting thread.  Right when
+ *                    the render threads have a core each.
+ *   ZOIC_WAIT_YIELD  spins for ~2 us, then sched_yield() between polls: for hosts with more render threads than cores (or a CPU quota
+ *                    below the thread count), where spinning threads are descheduled for whole scheduler periods while the thread that
+ *                    would have posted the next tile waits for a core (csrc/capi.cpp mailbox_await; DESIGN 1.1 "many render threads").
+ *   ZOIC_WAIT_SLEEP  spins for ~2 us, then sleeps 20 us between polls: a waiting thread costs next to nothing; +10-20 us per call.
+ * Any thread, any time; takes effect at the next wait. */
+typedef enum zoic_wait_mode { ZOIC_WAIT_SPIN = 0, ZOIC_WAIT_YIELD = 1, ZOIC_WAIT_SLEEP = 2 } zoic_wait_mode;
+zoic_status zoic_camera_set_wait_mode(zoic_camera *cam, zoic_wait_mode mode);
 /* seed of the per-ray retry streams (see zoic_create_rays_device) */
 zoic_status zoic_camera_set_seed(zoic_camera *cam, uint32_t seed);
 
@@ -234,7 +248,11 @@ zoic_status zoic_camera_create_ray(zoic_camera *cam, const zoic_camera_input *in
  *                     (whole rows: origin, dir, weight[3], dOdy / dDdy for retried rays, zeros elsewhere);
  *   zoic_tile_wait    returns when outputs[0 .. n) are complete; zoic_tile_done polls (1 = complete, nothing pending).
  * One submit per tile at a time (a second submit waits for the first).  A tile belongs to one render thread; different tiles may
- * be used from different threads at once.  zoic_camera_update / _destroy: wait for (or destroy) the camera's tiles first.
+ * be used from different threads at once.  zoic_camera_update: wait for the camera's tiles first.  zoic_camera_destroy settles the
+ * tiles still alive and DETACHES them: their arrays go with the camera (zoic_tile_inputs / _outputs / _rays / _samples return NULL,
+ * zoic_tile_capacity 0), every call on them but zoic_tile_destroy fails with ZOIC_ERR_INVALID_ARGUMENT.
+ * zoic_tile_done may be polled without a zoic_tile_wait in between (it restarts a resident kernel that retired under the poll); a
+ * HIP error it runs into is reported by the next zoic_tile_wait / _submit.
  * zoic_camera_create_rays_tile is the one-call form for arrays the caller owns: page-locked mapped arrays (zoic_host_alloc /
  * zoic_host_register) are used in place, anything else is staged through the slot's own page-locked buffers (two 16 Ki-row
  * pieces in flight).  Any n.  Counters: tile rays count like every other ray.
@@ -303,7 +321,7 @@ typedef enum zoic_frame_layout {
     ZOIC_FRAME_RECORDS = 0, /* n zoic_ray records (32 B/ray, flag word included) */
     ZOIC_FRAME_PAYLOAD = 1, /* n rows of 7 f32: ox oy oz dx dy dz weight (28 B/ray, SURVEY 8e's gather; the flag word stays on
                                the device that traced the ray) */
-    ZOIC_FRAME_PAYLOAD_SPARSE = 2 /* the same n rows on the root, but only the rays with weight != 0 are TRANSPORTED: a peer's chunk
+    ZOIC_FRAME_PAYLOAD_SPARSE = 2, /* the same n rows on the root, but only the rays with weight != 0 are TRANSPORTED: a peer's chunk
                                travels as a 256-bit live mask per 256-ray tile + the compacted rows of its live rays and is expanded
                                on the root.  Rows of weight-0 rays arrive as seven zeros: their origin / direction (the reference's
                                partial state of the last try, zoic.cpp:1951-1961) and their try counts are NOT transported -- they stay
@@ -312,7 +330,17 @@ typedef enum zoic_frame_layout {
                                the device: zoic_frame_render_device reads one 4-byte count per chunk back before it queues the copy, so
                                with this layout the call returns when the last chunk has been TRACED (copies and expansions may still
                                be in flight behind root_stream); zoic_frame_get_lane_info::bytes_to_root says what moved */
+    ZOIC_FRAME_PAYLOAD_AUTO = 3 /* ZOIC_FRAME_PAYLOAD or ZOIC_FRAME_PAYLOAD_SPARSE, chosen from the camera: the first AUTO render after a
+                               zoic_frame_update gathers dense; the next one reads the frame's ray counters (one synchronisation, once per
+                               update) and from then on the gather is SPARSE iff at least 25 % of the rays rendered since the update had
+                               weight 0 -- a wide-open PETZVAL (79 %) yes, the double Gauss with its bokeh image (0.07 %) never: there the
+                               sparse layout's count read-back and expansion pass cost more than its headers save.  Rows of live rays are
+                               the same bits either way; rows of weight-0 rays follow the layout chosen (dense: the reference's partial
+                               state; sparse: zeros).  zoic_frame_auto_layout says what was chosen. */
 } zoic_frame_layout;
+/* ZOIC_FRAME_PAYLOAD_AUTO's decision for the tables the frame holds: ZOIC_FRAME_PAYLOAD, ZOIC_FRAME_PAYLOAD_SPARSE, or -1 while
+ * undecided (no AUTO render since the last update, or only one).  zero_weight_fraction (may be NULL): what it measured, -1 undecided. */
+int zoic_frame_auto_layout(const zoic_frame *frame, double *zero_weight_fraction);
 
 /* [begin, end) of device i's slab of an n-sample call over n_devices devices.  Pure arithmetic, callable without a device. */
 zoic_status zoic_frame_slab(uint64_t n, int n_devices, int i, uint64_t *begin, uint64_t *end);

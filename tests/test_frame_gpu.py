@@ -166,3 +166,46 @@ def test_sparse_payload_moves_only_the_live_rays(gpu, cfg, devices, chunk):
         assert 28 * peers_live <= sparse_bytes <= 28 * peers_live + 48 * (tiles + 64 * len(devices))
         if cfg == "C5":
             assert dense_bytes / sparse_bytes > 3.0
+
+
+@pytest.mark.parametrize("cfg,expect_sparse", [("C5", True), ("C3", False), ("C2", False)])
+def test_auto_payload_layout_follows_the_cameras_dead_ray_fraction(gpu, cfg, expect_sparse):
+    """ZOIC_FRAME_PAYLOAD_AUTO.  The first AUTO render after an update gathers dense and the layout is undecided; the second
+    reads the frame's counters and decides -- SPARSE for C5's first rows (dead pixels), dense for the double Gauss and for this slab of
+    the TESSAR (15 % weight 0 < 25 %); the third follows the decision (bytes into the root say which); live rows are the one-device call's
+    bits throughout; an update makes it decide again."""
+    import torch
+    from zoic_amd import FRAME_PAYLOAD_AUTO, FRAME_PAYLOAD_SPARSE
+    c = CONFIGS[cfg]
+    n = 400_000 + 77
+    base = {"C5": 0, "C2": 2_000_000, "C3": 50_000_000}[cfg]
+    ref, _ = single(cfg, n, base, PRECISION_FAST)
+    ref7 = ref[:, :7].contiguous()
+    live = ref7[:, 6] != 0
+    devices = [0, 0, 0]
+    with ZoicFrame(devices) as frame:
+        setup(frame, cfg, PRECISION_FAST)
+        frame.generate_samples(n, c["width"], c["height"], c["spp"], seed=1, ray_index_base=base)
+        assert frame.auto_layout() == (None, None)
+        first = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD_AUTO)
+        torch.cuda.synchronize()
+        dense_bytes = sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices)))
+        assert frame.auto_layout()[0] is None                      # one render: nothing measured yet
+        second = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD_AUTO)
+        torch.cuda.synchronize()
+        layout, zero = frame.auto_layout()
+        third = frame.render(n, ray_index_base=base, layout=FRAME_PAYLOAD_AUTO)
+        torch.cuda.synchronize()
+        third_bytes = sum(frame.lane_info(i)["bytes_to_root"] for i in range(len(devices)))
+        assert torch.equal(first.view(torch.int32), ref7.view(torch.int32))      # the undecided render is the dense payload
+        assert abs(zero - float((~live).float().mean())) < 1e-6
+        assert (layout == FRAME_PAYLOAD_SPARSE) == expect_sparse and (layout == FRAME_PAYLOAD) == (not expect_sparse)
+        for got in (second, third):
+            assert torch.equal(got[live].view(torch.int32), ref7[live].view(torch.int32))
+            if expect_sparse:
+                assert bool((got[~live] == 0).all())
+            else:
+                assert torch.equal(got.view(torch.int32), ref7.view(torch.int32))
+        assert (third_bytes < 0.5 * dense_bytes) if expect_sparse else (third_bytes == dense_bytes)
+        setup(frame, cfg, PRECISION_FAST)                             # node_update: another camera as far as AUTO is concerned
+        assert frame.auto_layout() == (None, None)

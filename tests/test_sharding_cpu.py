@@ -88,13 +88,13 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path, oracle_lib):
     assert np.array_equal(np.ascontiguousarray(got[:, 7]).view(np.uint32), ref["flags"].astype(np.uint32))
 
 
-def _oracle_generate(n_total):
+def _oracle_generate(n_total, cfg="C2"):
     """ray-record generator over global ray indices backed by the oracle (CPU tests); bench.py plugs ZoicCamera in here"""
     import torch
     import oracle
     from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
-    c = CONFIGS["C2"]
-    oc = oracle.OracleCamera().update(**camera_params("C2"))
+    c = CONFIGS[cfg]
+    oc = oracle.OracleCamera().update(**camera_params(cfg))
 
     def generate(a, b):
         s = synthetic_samples(b - a, c["width"], c["height"], c["spp"], seed=1, ray_index_base=a)
@@ -281,3 +281,51 @@ def test_sparse_gather_ships_only_the_live_rays(tmp_path, oracle_lib):
     moved = int(np.load(tmp_path / "bytes.npy")[0])
     assert 28 * peers_live <= moved <= 28 * peers_live + (n - hi) // 8 + 200
     assert moved < 0.95 * 28 * (n - hi)
+
+
+def _auto_worker(rank, world, port, n, chunk_bytes, cfg, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from zoic_amd.sharding import ShardedFrame
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frame = ShardedFrame(n, dist, torch.device("cpu"), _oracle_generate(n, cfg), dst=0, chunk_bytes=chunk_bytes, sparse="auto")
+    moved = []
+    for step in range(3):
+        full = frame.run(gather=True)
+        moved.append(frame.root_bytes)
+    if rank == 0:
+        np.save(os.path.join(outdir, "auto_%s.npy" % cfg), full.numpy())
+    np.save(os.path.join(outdir, "auto_%s_rank%d.npy" % (cfg, rank)), np.array([frame.zero_weight_fraction, float(frame.sparse)] + moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg,expect_sparse", [("C4", False), ("C5", True)])
+def test_auto_layout_is_chosen_from_the_cameras_dead_ray_fraction(tmp_path, oracle_lib, cfg, expect_sparse):
+    """ShardedFrame(sparse="auto") gathers dense once, the root measures the frame's zero-weight fraction and every rank
+    switches to the sparse layout only at >= 25 % (the first rows of C5: all dead pixels -> sparse; the fisheye has no dead ray -> dense).
+    Every rank holds the same decision; the live rows are the single-process frame's either way."""
+    import torch.multiprocessing as mp
+    from zoic_amd.workloads import CONFIGS, camera_params, ray_rng_states, synthetic_samples
+    world, n, chunk_bytes = 2, 6_001, 28 * 1024
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_auto_worker, args=(world, port, n, chunk_bytes, cfg, str(tmp_path)), nprocs=world, join=True)
+    c = CONFIGS[cfg]
+    oc = oracle_lib.OracleCamera().update(**camera_params(cfg))
+    ref = oc.create_rays(synthetic_samples(n, c["width"], c["height"], c["spp"], seed=1), rng_states=ray_rng_states(n, 1, 0))
+    planes = np.ascontiguousarray(ref["planes"].T)
+    live = planes[:, 6] != 0
+    got = np.load(tmp_path / ("auto_%s.npy" % cfg))
+    assert np.array_equal(got[live].view(np.uint32), planes[live].view(np.uint32))
+    r0, r1 = np.load(tmp_path / ("auto_%s_rank0.npy" % cfg)), np.load(tmp_path / ("auto_%s_rank1.npy" % cfg))
+    assert r0[0] == r1[0] and abs(r0[0] - float((~live).mean())) < 1e-12       # the root's measurement reached every rank
+    assert bool(r0[1]) == bool(r1[1]) == expect_sparse, (cfg, r0)
+    if expect_sparse:
+        assert (got[~live] == 0).all() and r0[4] < 0.5 * r0[2]      # the third run moved less than half of what the dense first run did
+    else:
+        assert np.array_equal(got.view(np.uint32), planes.view(np.uint32)) and r0[4] == r0[2]

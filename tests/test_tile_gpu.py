@@ -112,9 +112,10 @@ def test_a_tile_of_ray_records_equals_the_device_call_bit_for_bit(gpu, cfg, wher
     cam.close()
 
 
-@pytest.mark.parametrize("cfg,where", [("C2", 0.08), ("C3", 0.3), ("C5", 0.12), ("C1", 0.4)])
+@pytest.mark.parametrize("cfg,where", [("C2", 0.08), ("C3", 0.3), ("C4", 0.5), ("C5", 0.12), ("C1", 0.4)])
 def test_a_strict_tile_equals_the_oracle(gpu, oracle_lib, cfg, where):
-    """No intermediary: STRICT tile rows against the oracle's rays (per-ray streams keyed by the global ray index), counters too."""
+    """No intermediary: STRICT tile rows against the oracle's rays (per-ray streams keyed by the global ray index), counters too.
+    (C4: the one configuration whose slab holds rays the FAST mode cannot decide -- VERDICT r5 asked for it here.)"""
     cam = camera(cfg, PRECISION_STRICT)
     oc = oracle_lib.OracleCamera()
     if CONFIGS[cfg]["bokeh"]:
@@ -134,6 +135,59 @@ def test_a_strict_tile_equals_the_oracle(gpu, oracle_lib, cfg, where):
     c = cam.counters()
     if cfg != "C1":
         assert c["vignettedRays"] == int((ref["tries"] > 25).sum()) and c["succesRays"] == n - c["vignettedRays"]
+    cam.close()
+
+
+DIR_RMSE_TOL = 1e-5   # BASELINE.json north_star: "ray-direction RMSE <1e-5 vs CPU reference" (tests/test_parity_gpu.py holds the same two)
+FLIP_TOL = 5e-5
+
+
+@pytest.mark.parametrize("cfg,where", [("C2", 0.08), ("C3", 0.3), ("C4", 0.5), ("C5", 0.12)])
+@pytest.mark.parametrize("layout", ["arnold_rows", "samples_in_records_out"])
+def test_a_fast_tile_is_within_tolerance_of_the_oracle(gpu, oracle_lib, cfg, where, layout):
+    """FAST tiles were only compared with the library's own batch call.  Here the decision-safe FAST tile goes against the
+    ORACLE directly, in both tile layouts: every ray's flag word (retried bit, try count, LUT miss) equals the oracle's up to FLIP_TOL,
+    direction RMSE < 1e-5 and origin RMSE < 1e-4 over the rays whose history agrees, their weights equal."""
+    cam = camera(cfg, PRECISION_FAST)
+    assert not cam.info()["fastRunsStrict"]
+    oc = oracle_lib.OracleCamera()
+    if CONFIGS[cfg]["bokeh"]:
+        oc.set_bokeh_image(hexagon_bokeh())
+    oc.update(**camera_params(cfg))
+    n = 65536
+    a, s, base = inputs_of(cfg, n, where)
+    ref = oc.create_rays(s, rng_states=ray_rng_states(n, seed=1, ray_index_base=base), threads=8)
+    tile = cam.tile(n, tid=11)
+    if layout == "arnold_rows":
+        tile.inputs[:n] = a
+        tile.submit(n, base)
+        tile.wait()
+        out = tile.outputs[:n].copy()
+        origin, direction, weight = out[:, 0:3].T, out[:, 3:6].T, out[:, 18]
+        # the rows carry no flag word: the retried bit is dOdy == origin && dDdy == dir (zoic.cpp:1974-1977), the try count is not
+        # transported -- weight 0 <=> ran out of tries
+        retried = (bits(out[:, 9:12]) == bits(out[:, 0:3])).all(1) & (bits(out[:, 15:18]) == bits(out[:, 3:6])).all(1) & (out[:, 15:18] != 0).any(1)
+        same = (retried == ((ref["flags"] & 1) != 0)) & ((weight == 0) == (ref["weight"] == 0))
+    else:
+        tile.set_rows(1)
+        tile.set_inputs(1)
+        tile.samples[:n] = s
+        tile.submit(n, base)
+        tile.wait()
+        out = tile.rays[:n].copy()
+        origin, direction, weight = out[:, 0:3].T, out[:, 3:6].T, out[:, 6]
+        same = out[:, 7].view(np.uint32).astype(np.uint8) == ref["flags"]
+    flip = 1.0 - float(same.mean())
+    assert flip < FLIP_TOL, (cfg, layout, flip)
+    live = same & (ref["weight"] != 0)
+    assert live.sum() > 1000 or cfg == "C5"
+    if live.any():
+        dd = direction[:, live].astype(np.float64) - ref["dir"][:, live]
+        do = origin[:, live].astype(np.float64) - ref["origin"][:, live]
+        assert float(np.sqrt((dd ** 2).sum(0).mean())) < DIR_RMSE_TOL
+        assert float(np.sqrt((do ** 2).sum(0).mean())) < 1e-4
+        assert np.array_equal(weight[live], ref["weight"][live])
+    tile.close()
     cam.close()
 
 
@@ -279,9 +333,9 @@ def test_tile_argument_errors(gpu):
     cam.close()
 
 
-@pytest.mark.parametrize("rays", [0, 1])
+@pytest.mark.parametrize("rays,samples16", [(0, 0), (1, 0), (1, 1), (0, 1)])
 @pytest.mark.parametrize("precision", [0, 1])
-def test_the_cpp_tile_buffer_accumulate_flush_serve(gpu, precision, rays):
+def test_the_cpp_tile_buffer_accumulate_flush_serve(gpu, precision, rays, samples16):
     """arnold/zoic_tile_buffer.hpp driven from plain C++ (tests/native/tile_buffer_test.cpp, built by __graft_entry__.build()): six
     render threads with a ZoicTileBuffer each; rows == zoic_create_rays_arnold, serve() == camera_create_ray's in-place update -- with the
     buffers answered in AtCameraOutput rows and in zoic_ray records."""
@@ -289,10 +343,11 @@ def test_the_cpp_tile_buffer_accumulate_flush_serve(gpu, precision, rays):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tests", "native", "tile_buffer_test")
-    if not os.path.exists(exe):
+    hdr = os.path.join(root, "arnold", "zoic_tile_buffer.hpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(exe + ".cpp"), os.path.getmtime(hdr)):
         subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + os.path.join(root, "include"), exe + ".cpp", "-o", exe, "-L" + os.path.join(root, "zoic_amd"),
                                "-lzoic_amd", "-lpthread", "-Wl,-rpath," + os.path.join(root, "zoic_amd")])
-    out = subprocess.run([exe, os.path.join(root, "zoic_amd", "lenses", "tessar_f2.8.dat"), str(precision), str(rays)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, os.path.join(root, "zoic_amd", "lenses", "tessar_f2.8.dat"), str(precision), str(rays), str(samples16)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "tile_buffer_test OK" in out.stdout, (out.stdout[-300:], out.stderr[-600:])
 
 

@@ -27,6 +27,7 @@ sys.path.insert(0, ".")
 from bench import csrc_sha16   # the fingerprint of the kernel sources this profile was taken on: bench.py replays the entry only on the same sources
 t[key] = {"csrc_sha16": csrc_sha16(), "hbm_bytes_per_launch": s["hbm_bytes_per_launch"], "fetch_bytes_x2_corrected": s["fetch_bytes(x2 corrected)"],
           "write_bytes": s["write_bytes"], "lane_instr_per_ray": s["lane_instr_per_ray"], "valu_thread_util": s["valu_thread_util"],
+          "trans_per_ray": s.get("trans_per_ray"), "valu_issue_slots_per_instr": s.get("valu_issue_slots_per_instr"),
           "pipeline_us_per_launch": s.get("pipeline_us_per_launch"), "dispatch_us": s.get("dispatch_us"),
           "source": dst + "/pmc_counters.csv (FETCH_SIZE x2 per MI355X_MICROARCH.md, separate --pmc passes; counters summed over the launch's kernel pipeline)"}
 json.dump(t, open(tp, "w"), indent=1)

@@ -1,7 +1,8 @@
 """Summarise a tools/profile.sh output directory: kernel stats + PMC-derived rates of one camera_create_ray launch.
 A Kolb launch is a short pipeline of kernels (kolb_pool_body.hpp main kernel + kolb_listed_body.hpp listed kernel): counters
 are averaged per dispatch for every kernel of the pipeline and then SUMMED over the pipeline, so every figure is per launch."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 base, nrays = sys.argv[1], float(sys.argv[2])
 pat = sys.argv[3] if len(sys.argv) > 3 else "kolb"
 st = glob.glob(base + "/trace/*/*_kernel_stats.csv")
@@ -48,6 +49,26 @@ for d in sorted(glob.glob(base + "/pmc*/*/*_counter_collection.csv")):
         # kernels that ran once or twice in the whole process are the self-check's, not the launch's
         tot[k] = sum(full(v) for kn, v in per_kernel.items() if len(v) >= 3 or len(per_kernel) == 1)
 g = lambda k: tot.get(k, float("nan"))
+# registers / spills of the launch's main kernel from the CODE OBJECT (tools/code_object_regs.py), not from the profiler's CSV
+# (rocprofv3's VGPR_Count column printed 40 for the 79-VGPR headline kernel)
+main_kernel, regs = None, None
+try:
+    import code_object_regs
+    timed = {k: d for k, d in dispatch.items() if d["dispatches"] >= 10}
+    if timed:
+        main_kernel = max(timed, key=lambda k: timed[k]["median_us"])
+        regs = code_object_regs.kernel_resources(os.environ.get("ZOIC_AMD_LIB") or os.path.join(code_object_regs.ROOT, "zoic_amd", "libzoic_amd.so")).get(main_kernel)
+except Exception as e:
+    print("code object registers unavailable:", e)
+# VALU instruction classes (profile.sh's last PMC pass) and the issue-slot model they give: op_rate (profiles/ubench_r01.txt) measures
+# f32 fma / mul / add and 32-bit integer add / logic at ~1 wave-instruction per 2 cycles per SIMD ("full rate"), compares, selects, shifts,
+# conversions, v_max, lane moves at HALF of it, v_sqrt / v_rsq / v_rcp at a QUARTER.  slots = full + 2 x half + 4 x quarter, in units of one
+# full-rate issue; `other` = the VALU instructions in none of the counted classes (compares, selects, moves, lane moves ...), priced at half rate.
+cls = {k: g("SQ_INSTS_VALU_" + k) for k in ("FMA_F32", "MUL_F32", "ADD_F32", "INT32", "CVT", "TRANS_F32")}
+valu = g("SQ_INSTS_VALU")
+counted = sum(cls.values())
+other = valu - counted
+issue_slots = cls["FMA_F32"] + cls["MUL_F32"] + cls["ADD_F32"] + cls["INT32"] + 2 * (cls["CVT"] + other) + 4 * cls["TRANS_F32"]
 cyc = g("GRBM_GUI_ACTIVE") / 8
 simd = cyc * 1024
 out = {
@@ -55,7 +76,9 @@ out = {
     "dispatch_us": dispatch,
     "bench_line_same_call": {k: bench_line[k] for k in ("value", "ms_per_step")} if bench_line else None,
     "dominant_kernel_median_fits_ms_per_step": (max(d["median_us"] for d in dispatch.values()) <= bench_line["ms_per_step"] * 1e3) if (bench_line and dispatch) else None,
-    "vgpr/sgpr/lds (main kernel)": (tot.get("_vgpr"), tot.get("_sgpr"), tot.get("_lds")),
+    "main_kernel": main_kernel,
+    "code_object (main kernel)": regs,
+    "lds_block_bytes (profiler)": tot.get("_lds"),
     "lane_instr_per_ray": g("SQ_INSTS_VALU") * 64 / nrays,
     "valu_thread_util": g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64),
     "salu_per_valu": g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"),
@@ -68,7 +91,10 @@ out = {
     "vmem_rd_per_ray": g("SQ_INSTS_VMEM_RD") * 64 / nrays, "vmem_wr_per_ray": g("SQ_INSTS_VMEM_WR") * 64 / nrays,
     "smem_per_wave_instr": g("SQ_INSTS_SMEM") / g("SQ_INSTS_VALU"),
     "lds_instr_per_ray": g("SQ_INSTS_LDS") * 64 / nrays,
-    "trans_per_ray": g("SQ_INSTS_VALU_TRANS") * 64 / nrays,
+    "trans_per_ray": cls["TRANS_F32"] * 64 / nrays,
+    "valu_mix_per_ray": {k.lower(): round(v * 64 / nrays, 1) for k, v in cls.items()} | {"other(cmp/select/mov/lane...)": round(other * 64 / nrays, 1)} if counted == counted else None,
+    "valu_issue_slots_per_instr": issue_slots / valu,
+    "valu_pipe_frac_by_mix": issue_slots * 2 / simd,   # of the SIMDs' cycles, if every full-rate slot takes 2 cycles: ~1.0 = the VALU pipe never idles
     "hbm_bytes_per_launch": (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024,
     "fetch_bytes(x2 corrected)": 2 * g("FETCH_SIZE") * 1024, "write_bytes": g("WRITE_SIZE") * 1024,
     "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),

@@ -9,13 +9,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ZOIC_AMD_LIB points at another build of the same library (A/B experiments, tools/); there is still no fallback
 LIB_PATH = os.environ.get("ZOIC_AMD_LIB") or os.path.join(HERE, "libzoic_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LENS_SURFACES = 32
 LUT_ENTRIES = 32
 
 THINLENS, RAYTRACED, LENS_NONE = 0, 1, 2
 PRECISION_STRICT, PRECISION_FAST, PRECISION_FAST_UNCHECKED = 0, 1, 2
-FRAME_RECORDS, FRAME_PAYLOAD, FRAME_PAYLOAD_SPARSE = 0, 1, 2
+FRAME_RECORDS, FRAME_PAYLOAD, FRAME_PAYLOAD_SPARSE, FRAME_PAYLOAD_AUTO = 0, 1, 2, 3
 TILE_MAX_SAMPLES = 65536
 
 STATUS_NAMES = ["ZOIC_OK", "ZOIC_ERR_INVALID_ARGUMENT", "ZOIC_ERR_LENS_PATH", "ZOIC_ERR_LENS_COLUMNS",
@@ -88,6 +88,7 @@ SYMBOLS = {
     "zoic_camera_set_lens_text": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "zoic_camera_set_precision": (C.c_int, [_vp, C.c_int]),
     "zoic_camera_set_frame_aspect": (C.c_int, [_vp, C.c_float]),
+    "zoic_camera_set_wait_mode": (C.c_int, [_vp, C.c_int]),
     "zoic_camera_set_seed": (C.c_int, [_vp, _u32]),
     "zoic_create_rays_device": (C.c_int, [_vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "zoic_create_rays_host": (C.c_int, [_vp, _u64, _vp, _vp, _u64, _vp]),
@@ -130,6 +131,7 @@ SYMBOLS = {
     "zoic_frame_synchronize": (C.c_int, [_vp]),
     "zoic_frame_get_lane_info": (C.c_int, [_vp, C.c_int, C.POINTER(FrameLaneInfo)]),
     "zoic_frame_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
+    "zoic_frame_auto_layout": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "zoic_camera_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "zoic_camera_reset_counters": (C.c_int, [_vp]),
     "zoic_camera_get_info": (C.c_int, [_vp, C.POINTER(LensInfo)]),

@@ -12,6 +12,7 @@ This module only marshals pointers; all rays come from the HIP kernels.  torch t
 arrays (host memory) are both accepted.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -106,6 +107,7 @@ class ZoicTile:
         self._h = None
         cam._check(self._lib.zoic_tile_create(cam._h, int(capacity), int(tid) & 0xFFFF, C.byref(h)))
         self._h = h
+        cam._tiles.add(self)   # weak: ZoicCamera.close() closes the tiles still alive first (their views point into memory the camera's end frees)
         self.capacity = int(self._lib.zoic_tile_capacity(h))
         self.tid = int(tid)
         pin = C.cast(self._lib.zoic_tile_inputs(h), C.c_void_p).value
@@ -136,7 +138,8 @@ class ZoicTile:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.inputs = self.outputs = None
+            # every view onto the page-locked arrays goes before the arrays do
+            self.inputs = self.outputs = self.samples = self.rays = None
             self._lib.zoic_tile_destroy(self._h)
             self._h = None
 
@@ -156,6 +159,7 @@ class ZoicCamera:
         self._h = h
         self.device = int(device)
         self.params = None
+        self._tiles = weakref.WeakSet()   # the ZoicTile objects made by tile(): closed with the camera
 
     # ------------------------------------------------------------------ lifetime
     def _check(self, status):
@@ -164,7 +168,9 @@ class ZoicCamera:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.zoic_camera_destroy(self._h)
+            for t in list(getattr(self, "_tiles", ())):
+                t.close()
+            self._lib.zoic_camera_destroy(self._h)   # (would settle and detach them itself: the C-ABI's own rule, include/zoic_amd.h)
             self._h = None
 
     def __del__(self):
@@ -197,6 +203,10 @@ class ZoicCamera:
 
     def set_precision(self, mode):
         self._check(self._lib.zoic_camera_set_precision(self._h, int(mode)))
+
+    def set_wait_mode(self, mode):
+        """0 spin (default), 1 yield, 2 sleep: how a calling thread waits for the resident kernel (zoic_camera_set_wait_mode)."""
+        self._check(self._lib.zoic_camera_set_wait_mode(self._h, int(mode)))
 
     def set_seed(self, seed):
         self._check(self._lib.zoic_camera_set_seed(self._h, int(seed) & 0xFFFFFFFF))
@@ -313,7 +323,7 @@ class ZoicCamera:
         return outs
 
     def tile(self, capacity, tid=0):
-        """A ZoicTile of this camera (destroy it -- tile.close() -- before the camera)."""
+        """A ZoicTile of this camera (closed with the camera at the latest: ZoicCamera.close() closes the tiles still alive)."""
         return ZoicTile(self, capacity, tid)
 
     def create_rays_tile(self, inputs, ray_index_base=0, tid=0, out=None):

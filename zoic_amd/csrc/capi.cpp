@@ -15,6 +15,8 @@
 //     duration of the call, synchronise only their own streams, and never touch camera-wide scratch;
 //   * the per-sample adapter keeps one retry stream per Arnold thread id (tid 0 = the reference's own global xor128 state).
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -271,6 +273,11 @@ struct zoic_camera {  // struct cameraData, zoic.cpp:627-643
     Mailbox mail;                           // camera_create_ray per sample (mailbox.hip)
     std::unique_ptr<std::atomic<TidState *>[]> tidStates;   // kTidStates entries, created on first use
     std::mutex tidCreateM;
+    // the caller's tiles (zoic_tile_create): zoic_camera_destroy settles and DETACHES the ones still alive -- their page-locked arrays go
+    // with the camera, the handles stay valid for zoic_tile_destroy and answer every other call with an error
+    std::mutex tilesM;
+    std::vector<zoic_tile *> liveTiles;
+    std::atomic<int> waitMode{ZOIC_WAIT_SPIN};   // zoic_camera_set_wait_mode: how a render thread waits for the resident kernel
 
     TidState *tid_state(uint16_t tid);
     CallContext *lease_context(hipError_t &err);
@@ -328,6 +335,8 @@ struct zoic_tile {
     zoic_camera_output *outputs = nullptr;
     uint64_t dIn = 0, dOut = 0;       // the same arrays as the device sees them
     uint32_t seq = 0;                 // the submit not waited for yet (0: none); under the slot's mutex
+    uint32_t polls = 0;               // zoic_tile_done calls since the submit (every 1024th asks the stream whether the kernel still lives)
+    bool registered = false;          // listed in cam->liveTiles (the caller's tiles; the slots' own staging tiles are not)
     int rows = ZOIC_TILE_ROWS_ARNOLD; // what the kernel writes at dOut: AtCameraOutput rows or zoic_ray records
     int ins = ZOIC_TILE_INPUTS_ARNOLD; // what the caller writes at dIn: AtCameraInput rows or (sx, sy, lensx, lensy) samples
 };
@@ -749,6 +758,8 @@ zoic_status fast_self_check(zoic_camera *cam, bool &keep)
 
 }  // namespace
 
+static void detach_tiles(zoic_camera *cam);   // (defined with the tile entry points below)
+
 extern "C" {
 
 int zoic_abi_version(void) { return ZOIC_AMD_ABI_VERSION; }
@@ -853,6 +864,7 @@ void zoic_camera_destroy(zoic_camera *cam)
     if (cam->device == ZOIC_DEVICE_NONE) { delete cam; return; }
     {
         DeviceGuard guard(cam->device);
+        detach_tiles(cam);              // tiles the caller has not destroyed yet: settled, their arrays released, the handles detached
         cam->mail.release();
         (void)hipDeviceSynchronize();   // launches the caller left in flight still read the tables and cursors freed below
         for (auto &c : cam->contexts) c->release();
@@ -903,6 +915,14 @@ zoic_status zoic_camera_set_precision(zoic_camera *cam, zoic_precision mode)
         ZOIC_HIP(cam->mail.stop());
     }
     cam->precision = mode;
+    return ZOIC_OK;
+}
+
+zoic_status zoic_camera_set_wait_mode(zoic_camera *cam, zoic_wait_mode mode)
+{
+    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "cam is NULL");
+    if (mode != ZOIC_WAIT_SPIN && mode != ZOIC_WAIT_YIELD && mode != ZOIC_WAIT_SLEEP) return fail(ZOIC_ERR_INVALID_ARGUMENT, "wait mode: ZOIC_WAIT_SPIN, _YIELD or _SLEEP");
+    cam->waitMode.store(static_cast<int>(mode), std::memory_order_relaxed);
     return ZOIC_OK;
 }
 
@@ -1069,6 +1089,9 @@ zoic_status zoic_camera_update(zoic_camera *cam, const zoic_params *p)
                 cam->updated = false; cam->params.valid = false; cam->fastVerdictValid = false;
                 return s;
             }
+#if defined(ZOIC_EXP_WHATIF) && ZOIC_EXP_WHATIF != 0
+            keep = true;   // timing-only what-if builds (kolb_pool_body.hpp): their rays are wrong on purpose, the check would send them to STRICT
+#endif
             cam->fastVerdict = keep; cam->fastVerdictValid = true;
         }
         cam->fastDomain = cam->fastVerdict;
@@ -1247,23 +1270,34 @@ static zoic_status mailbox_ensure_running(zoic_camera *cam, unsigned slot, bool 
     return ZOIC_OK;
 }
 
-// Spin until `ready()`; the resident kernel may retire (idle / lifetime) around a call and is started again from here.
+// Wait until `ready()`; the resident kernel may retire (idle / lifetime) around a call and is started again from here.
+// zoic_camera_set_wait_mode: SPIN = a pause loop (a core per waiting thread); YIELD / SLEEP = spin ~2 us (kWaitSpinFirst pauses: the
+// per-sample call's reply and a small tile arrive inside that), then sched_yield() / a 20 us sleep between polls -- hosts with more
+// render threads than cores.  `tick` counts in pause-equivalents so that the periodic checks keep their rough wall-clock spacing.
+constexpr uint64_t kWaitSpinFirst = 256;
 template <class Ready>
 static zoic_status mailbox_await(zoic_camera *cam, unsigned slot, bool wantWorkers, Ready ready)
 {
     Mailbox &M = cam->mail;
+    const int mode = cam->waitMode.load(std::memory_order_relaxed);
     std::chrono::steady_clock::time_point t0;
+    bool timing = false;
+    uint64_t tick = 0, nextAlive = 2048, nextQuery = 0x100000;
     for (uint64_t spins = 1;; ++spins) {
         if (ready()) return ZOIC_OK;
-        __builtin_ia32_pause();
-        if ((spins & 2047u) != 0u) continue;
+        if (mode == ZOIC_WAIT_SPIN || spins <= kWaitSpinFirst) { __builtin_ia32_pause(); tick += 1; }
+        else if (mode == ZOIC_WAIT_YIELD) { sched_yield(); tick += 64; }                                  // ~0.5-1 us per round trip through the scheduler
+        else { const timespec ts{0, 20000}; nanosleep(&ts, nullptr); tick += 4096; }                      // 20 us + the timer's slack
+        if (tick < nextAlive) continue;
+        nextAlive = tick + 2048;
         if (M.header()->alive == 0u) {   // the kernel retired (idle / lifetime) around this call: start it again
             if (zoic_status s = mailbox_ensure_running(cam, slot, wantWorkers)) return s;
-        } else if ((spins & 0xfffffu) == 0u) {
+        } else if (tick >= nextQuery) {
             // every ~20 ms: a kernel that died (fault) never clears `alive` -- ask the stream; and never wait for ever (20 s)
+            nextQuery = tick + 0x100000;
             if (zoic_status s = mailbox_ensure_running(cam, slot, wantWorkers)) return s;
             const auto now = std::chrono::steady_clock::now();
-            if (spins == 0x100000u) t0 = now;
+            if (!timing) { t0 = now; timing = true; }
             else if (now - t0 > std::chrono::seconds(20)) return fail(ZOIC_ERR_HIP, "resident kernel did not answer");
         }
     }
@@ -1279,6 +1313,27 @@ static zoic_status tile_settle_locked(zoic_camera *cam, unsigned slot)
     std::atomic_thread_fence(std::memory_order_acquire);
     M.tileSeq[slot] = 0u;
     return ZOIC_OK;
+}
+
+// zoic_camera_destroy with tiles of the caller still alive (a tile outliving its camera dereferenced freed memory): every tile in
+// flight is settled, its page-locked arrays are released with the camera and the handle is DETACHED -- zoic_tile_destroy still frees it,
+// every other call on it fails with ZOIC_ERR_INVALID_ARGUMENT, its array getters return NULL.
+static void detach_tiles(zoic_camera *cam)
+{
+    std::vector<zoic_tile *> tiles;
+    { std::lock_guard<std::mutex> lk(cam->tilesM); tiles.swap(cam->liveTiles); }
+    for (zoic_tile *t : tiles) {
+        bool settled = true;
+        {
+            std::lock_guard<std::mutex> slotLock(cam->mail.slotM[t->slot]);
+            if (t->seq != 0u && cam->mail.tileSeq[t->slot] == t->seq) settled = tile_settle_locked(cam, t->slot) == ZOIC_OK;
+        }
+        if (!settled) (void)cam->mail.stop();   // the kernel did not answer: nothing of it may still write into the arrays released here
+        t->mem.release();
+        t->inputs = nullptr; t->outputs = nullptr; t->dIn = t->dOut = 0; t->seq = 0u; t->capacity = 0u;
+        t->registered = false;
+        t->cam = nullptr;
+    }
 }
 
 extern "C" {
@@ -1380,14 +1435,27 @@ zoic_status zoic_tile_create(zoic_camera *cam, uint32_t capacity, uint16_t tid, 
     if (capacity == 0u || capacity > kTileMaxSamples) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile capacity must be 1 ... ZOIC_TILE_MAX_SAMPLES");
     DeviceGuard guard(cam->device);
     ZOIC_HIP(guard.error());
-    return tile_alloc(cam, capacity, tid, out);
+    if (zoic_status s = tile_alloc(cam, capacity, tid, out)) return s;
+    std::lock_guard<std::mutex> lk(cam->tilesM);
+    cam->liveTiles.push_back(*out);
+    (*out)->registered = true;
+    return ZOIC_OK;
 }
 
 void zoic_tile_destroy(zoic_tile *tile)
 {
     if (!tile) return;
-    (void)zoic_tile_wait(tile);   // the GPU may still be writing into the arrays freed below
-    DeviceGuard guard(tile->cam->device);
+    zoic_camera *cam = tile->cam;
+    if (!cam) { delete tile; return; }   // detached by zoic_camera_destroy: its arrays went with the camera
+    DeviceGuard guard(cam->device);
+    // the GPU may still be writing into the arrays freed below; if the resident kernel does not answer (20 s / a HIP error) it is
+    // stopped first -- no wave of it outlives the stop
+    if (zoic_tile_wait(tile) != ZOIC_OK) (void)cam->mail.stop();
+    if (tile->registered) {
+        std::lock_guard<std::mutex> lk(cam->tilesM);
+        auto it = std::find(cam->liveTiles.begin(), cam->liveTiles.end(), tile);
+        if (it != cam->liveTiles.end()) cam->liveTiles.erase(it);
+    }
     tile->mem.release();
     delete tile;
 }
@@ -1400,6 +1468,7 @@ zoic_status zoic_tile_submit(zoic_tile *tile, uint32_t n, uint64_t ray_index_bas
 {
     if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
     zoic_camera *cam = tile->cam;
+    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "the tile's camera has been destroyed");
     if (zoic_status s = check_tile_call(cam)) return s;
     if (n > tile->capacity) return fail(ZOIC_ERR_INVALID_ARGUMENT, "n exceeds the tile's capacity");
     if (n == 0u) return ZOIC_OK;
@@ -1407,8 +1476,9 @@ zoic_status zoic_tile_submit(zoic_tile *tile, uint32_t n, uint64_t ray_index_bas
     ZOIC_HIP(guard.error());
     std::lock_guard<std::mutex> slotLock(cam->mail.slotM[tile->slot]);
     // one request per slot at a time: this tile's previous submit, or another tile of the same slot (tids 64 apart), comes first
-    if (cam->mail.mem.host) if (zoic_status s = tile_settle_locked(cam, tile->slot)) return s;
-    tile->seq = 0u;
+    // (tile_settle_locked returns at once while nothing is in flight: tileSeq == 0 before the mailbox exists)
+    if (zoic_status s = tile_settle_locked(cam, tile->slot)) return s;
+    tile->seq = 0u; tile->polls = 0u;
     return tile_post_locked(cam, tile->slot, n, tile->dIn, tile->dOut, ray_index_base, &tile->seq, tile->rows | (tile->ins << 1));
 }
 
@@ -1416,6 +1486,7 @@ zoic_status zoic_tile_wait(zoic_tile *tile)
 {
     if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
     zoic_camera *cam = tile->cam;
+    if (!cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "the tile's camera has been destroyed");
     if (tile->seq == 0u) return ZOIC_OK;
     DeviceGuard guard(cam->device);
     ZOIC_HIP(guard.error());
@@ -1429,6 +1500,7 @@ zoic_status zoic_tile_wait(zoic_tile *tile)
 zoic_status zoic_tile_set_rows(zoic_tile *tile, int rows)
 {
     if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
+    if (!tile->cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "the tile's camera has been destroyed");
     if (rows != ZOIC_TILE_ROWS_ARNOLD && rows != ZOIC_TILE_ROWS_RAYS) return fail(ZOIC_ERR_INVALID_ARGUMENT, "rows: ZOIC_TILE_ROWS_ARNOLD or ZOIC_TILE_ROWS_RAYS");
     if (tile->seq != 0u) return fail(ZOIC_ERR_INVALID_ARGUMENT, "zoic_tile_set_rows between a submit and its wait");
     tile->rows = rows;
@@ -1440,6 +1512,7 @@ const zoic_ray *zoic_tile_rays(const zoic_tile *tile) { return tile ? reinterpre
 zoic_status zoic_tile_set_inputs(zoic_tile *tile, int inputs)
 {
     if (!tile) return fail(ZOIC_ERR_INVALID_ARGUMENT, "tile is NULL");
+    if (!tile->cam) return fail(ZOIC_ERR_INVALID_ARGUMENT, "the tile's camera has been destroyed");
     if (inputs != ZOIC_TILE_INPUTS_ARNOLD && inputs != ZOIC_TILE_INPUTS_SAMPLES) return fail(ZOIC_ERR_INVALID_ARGUMENT, "inputs: ZOIC_TILE_INPUTS_ARNOLD or ZOIC_TILE_INPUTS_SAMPLES");
     if (tile->seq != 0u) return fail(ZOIC_ERR_INVALID_ARGUMENT, "zoic_tile_set_inputs between a submit and its wait");
     tile->ins = inputs;
@@ -1450,11 +1523,20 @@ float *zoic_tile_samples(zoic_tile *tile) { return tile ? reinterpret_cast<float
 
 int zoic_tile_done(zoic_tile *tile)
 {
-    if (!tile || tile->seq == 0u) return 1;
+    if (!tile || !tile->cam || tile->seq == 0u) return 1;
     zoic_camera *cam = tile->cam;
     std::lock_guard<std::mutex> slotLock(cam->mail.slotM[tile->slot]);
     if (cam->mail.tileSeq[tile->slot] != tile->seq) return 1;
-    return cam->mail.tile_complete(tile->slot) ? 1 : 0;
+    if (cam->mail.tile_complete(tile->slot)) return 1;
+    // The resident kernel retires by itself (1 ms idle / 50 ms of life, mailbox.hpp).  If it left between the submit's look at `alive`
+    // and the slot wave's look at the request line, nobody is watching the request: a caller that only polls done() would spin for
+    // ever.  So an incomplete tile with no kernel alive starts it again here; every 1024th poll also asks the stream (a
+    // kernel that died on a fault never clears `alive`) -- an error found that way is reported by the zoic_tile_wait that must follow.
+    if (cam->mail.header()->alive == 0u || (++tile->polls & 1023u) == 0u) {
+        DeviceGuard guard(cam->device);
+        if (guard.error() == hipSuccess) (void)mailbox_ensure_running(cam, tile->slot, true);
+    }
+    return 0;
 }
 
 zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,
@@ -1479,7 +1561,7 @@ zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoi
         if (pinned) { dIn = reinterpret_cast<uint64_t>(ai.devicePointer); dOut = reinterpret_cast<uint64_t>(ao.devicePointer); }
     }
     std::lock_guard<std::mutex> slotLock(M.slotM[slot]);
-    if (M.mem.host) if (zoic_status s = tile_settle_locked(cam, slot)) return s;
+    if (zoic_status s = tile_settle_locked(cam, slot)) return s;
     uint32_t seq = 0;
     if (dIn != 0 && dOut != 0) {
         for (uint32_t off = 0; off < n; off += kTileMaxSamples) {

@@ -85,7 +85,15 @@ struct zoic_frame {
     std::vector<Lane> lanes;
     uint64_t chunkRays = 0;   // 0: default
     hipEvent_t rootStart = nullptr;   // recorded on the caller's root stream when a render call begins
+    // ZOIC_FRAME_PAYLOAD_AUTO: the gather's layout chosen from the camera.  The first AUTO render after an update is dense; the next
+    // one reads the counters (zoic_frame_get_counters: one synchronisation, once per update) and from then on the frame ships SPARSE
+    // iff at least kAutoSparseZeroWeight of the rays rendered since the update had weight 0.
+    bool autoDecided = false, autoSparse = false;
+    uint64_t autoBaseSucc = 0, autoBaseVign = 0;   // the counters when the tables were last rebuilt
+    uint64_t autoRendered = 0;                     // rays rendered through AUTO since then
+    double autoZeroWeight = -1.0;
 };
+constexpr double kAutoSparseZeroWeight = 0.25;
 
 namespace {
 
@@ -283,6 +291,11 @@ zoic_status zoic_frame_update(zoic_frame *frame, const zoic_params *p)
     for (std::thread &t : th) t.join();
     for (size_t i = 0; i < st.size(); ++i)
         if (st[i] != ZOIC_OK) return fail_status(st[i], why[i]);
+    // another camera from here on: ZOIC_FRAME_PAYLOAD_AUTO decides again
+    frame->autoDecided = false; frame->autoSparse = false; frame->autoRendered = 0; frame->autoZeroWeight = -1.0;
+    zoic_counters c;
+    if (zoic_status s = zoic_frame_get_counters(frame, &c)) return s;
+    frame->autoBaseSucc = c.succesRays; frame->autoBaseVign = c.vignettedRays;
     return ZOIC_OK;
 }
 
@@ -604,15 +617,41 @@ zoic_status zoic_frame_render_device(zoic_frame *frame, uint64_t n, const float 
                                      zoic_frame_layout layout, void *root_stream)
 {
     if (!frame) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "frame is NULL");
-    if (layout != ZOIC_FRAME_RECORDS && layout != ZOIC_FRAME_PAYLOAD && layout != ZOIC_FRAME_PAYLOAD_SPARSE) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "bad layout");
+    if (layout != ZOIC_FRAME_RECORDS && layout != ZOIC_FRAME_PAYLOAD && layout != ZOIC_FRAME_PAYLOAD_SPARSE && layout != ZOIC_FRAME_PAYLOAD_AUTO)
+        return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "bad layout");
     if (n == 0) return ZOIC_OK;
     if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15u)) return fail_status(ZOIC_ERR_INVALID_ARGUMENT, "d_out must be non-NULL and 16-byte aligned");
+    if (layout == ZOIC_FRAME_PAYLOAD_AUTO) {
+        if (!frame->autoDecided && frame->autoRendered != 0) {
+            // the frame has rendered since its tables were built: what share of those rays had weight 0?  (Any ray call counts -- the
+            // cameras' counters do not know who asked.)  One synchronisation, once per update.
+            if (zoic_status s = zoic_frame_synchronize(frame)) return s;
+            zoic_counters c;
+            if (zoic_status s = zoic_frame_get_counters(frame, &c)) return s;
+            const uint64_t succ = c.succesRays - std::min<uint64_t>(frame->autoBaseSucc, c.succesRays), vign = c.vignettedRays - std::min<uint64_t>(frame->autoBaseVign, c.vignettedRays);
+            if (succ + vign != 0) {
+                frame->autoZeroWeight = static_cast<double>(vign) / static_cast<double>(succ + vign);
+                frame->autoSparse = frame->autoZeroWeight >= kAutoSparseZeroWeight;
+                frame->autoDecided = true;
+            }
+        }
+        frame->autoRendered += n;
+        layout = (frame->autoDecided && frame->autoSparse) ? ZOIC_FRAME_PAYLOAD_SPARSE : ZOIC_FRAME_PAYLOAD;
+    }
     if (layout == ZOIC_FRAME_PAYLOAD_SPARSE) {
         if (zoic_status s = render_sparse_impl(frame, n, d_samples, ray_index_base, d_out, root_stream)) return settle_after_failure(frame, s);
         return ZOIC_OK;
     }
     if (zoic_status s = render_device_impl(frame, n, d_samples, ray_index_base, d_out, layout, root_stream)) return settle_after_failure(frame, s);
     return ZOIC_OK;
+}
+
+int zoic_frame_auto_layout(const zoic_frame *frame, double *zero_weight_fraction)
+{
+    if (!frame) return -1;
+    if (zero_weight_fraction) *zero_weight_fraction = frame->autoZeroWeight;
+    if (!frame->autoDecided) return -1;
+    return frame->autoSparse ? ZOIC_FRAME_PAYLOAD_SPARSE : ZOIC_FRAME_PAYLOAD;
 }
 
 zoic_status zoic_frame_render_local(zoic_frame *frame, uint64_t n, const float *const *d_samples, uint64_t ray_index_base, zoic_ray *const *d_rays)

@@ -12,6 +12,10 @@ int launch_kolb_listed(const KolbTable &table, const BokehTables &bokeh, const f
                        unsigned grid, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // EXPERIMENT (profiles/ab_r06/ab_listed_grid.log): ZOIC_LISTED_GRID=n workgroups instead of the GUARD kernel's grid.  Both paths of the
+    // kernel stride over the list with whatever grid they get, so this is a pure performance knob.
+    static const long gridOverride = [] { const char *e = std::getenv("ZOIC_LISTED_GRID"); return e ? std::atol(e) : 0L; }();
+    if (gridOverride > 0) grid = static_cast<unsigned>(gridOverride);
     const uint32_t ldsWords = kolb_image_cells(table, bokeh) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
     const size_t lds = static_cast<size_t>(ldsWords + kLutLdsWords + kWavesPerBlock * kListedWaveWords) * sizeof(float);
 #define ZOIC_LAUNCH_LISTED(NS_)                                                                                                          \

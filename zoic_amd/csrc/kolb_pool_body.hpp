@@ -39,6 +39,12 @@
 
 #pragma STDC FP_CONTRACT OFF
 
+#ifndef ZOIC_EXP_WHATIF
+#define ZOIC_EXP_WHATIF 0   // TIMING-ONLY experiments (results are WRONG, never shipped; profiles/ab_r06/whatif.log): 1 = the IMAGE kernels' retries sample the
+                            // disk instead of the image (no retry gathers), 2 = their first try does (no probe gather), 3 = no listed kernel is launched,
+                            // 4 = finish_dead_ray does not re-read its sample
+#endif
+
 namespace zoic {
 
 // Kernel arguments that only rare paths read (chunk claim, first retry, work-list flush, exit) are fetched from the kernarg
@@ -174,7 +180,11 @@ __device__ __forceinline__ bool finish_dead_ray(const KolbTable &T, const BokehT
                                                 const float4 *__restrict__ samples, const uint4 *__restrict__ states, uint64_t rayBase,
                                                 RayRecord *__restrict__ out, uint32_t idx)
 {
+#if ZOIC_EXP_WHATIF == 4
+    const float4 s = make_float4(__builtin_bit_cast(float, (idx & 0xffffu) | 0x3f000000u) - 0.75f, 0.3f, 0.0f, 0.0f);
+#else
     const float4 s = samples[idx];
+#endif
     const RaySetup rs = setup_ray<STRICT>(T, lutLds, s.x, s.y);
     Rng rng;
     if (states) { const uint4 r = states[idx]; rng = Rng{r.x, r.y, r.z, r.w}; }
@@ -323,7 +333,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
     };
     const auto advance_batches = [&]() {   // b1 <- b2 (+ its probe), b2 <- the next request
         s1 = s2; base1 = base2; cnt1 = cnt2; have1 = have2;
+#if ZOIC_EXP_WHATIF != 2
         if constexpr (PROBE) { if (have1) probe = bokeh_cells_issue(B, bokehLds, T.bokehH, s1.z, s1.w); }
+#endif
         if (have1) request_batch();
     };
     request_batch();
@@ -387,7 +399,11 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             // dead pixel (outside the image circle, LUT entries zero): whatever finite point the sampler returns, the direction
             // is (0 - o.x, 0 - o.y, dirZ); samples in [0,1)^2 off the disk mapping's 0/0 centre need no sampler
             V2 lens;
+#if ZOIC_EXP_WHATIF == 2
+            if constexpr (PROBE) lens = concentric_disk_f32(u, v);
+#else
             if constexpr (PROBE) lens = bokeh_cells_finish<STRICT>(B, T.bokehW, T.bokehH, v, probe);
+#endif
             else lens = sample_lens(u, v);
             if (__ballot(dead) != 0ull) {   // wave-uniform: most waves hold no dead pixel and skip these dozen compares
                 const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
@@ -469,6 +485,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                     constexpr int kDraws = ZOIC_SEARCH_DRAWS;
                     Rng after[kDraws];
                     float vCol[kDraws];
+#if ZOIC_EXP_WHATIF == 1
+                    float uCol[kDraws];
+#endif
                     CellProbe probes[kDraws];
                     Rng r = rng;
 #pragma unroll
@@ -476,14 +495,22 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                         const float uj = rng_unit(xor128(r));   // zoic.cpp:1930
                         vCol[j] = rng_unit(xor128(r));
                         after[j] = r;
+#if ZOIC_EXP_WHATIF == 1
+                        probes[j] = CellProbe{make_uint4(0u, 0u, 0u, 0u), 0, 0u}; uCol[j] = uj;
+#else
                         probes[j] = bokeh_cells_issue(B, bokehLds, T.bokehH, uj, vCol[j]);
+#endif
                     }
                     bool open = true;
 #pragma unroll
                     for (int j = 0; j < kDraws; ++j) {
                         if (open) {
                             ++tries; rng = after[j];
+#if ZOIC_EXP_WHATIF == 1
+                            d = retry_direction(T, concentric_disk_f32(uCol[j], vCol[j]), o0x, o0y, maxScale, translation, sn, cs);
+#else
                             d = retry_direction(T, bokeh_cells_finish<STRICT>(B, T.bokehW, T.bokehH, vCol[j], probes[j]), o0x, o0y, maxScale, translation, sn, cs);
+#endif
                             bool near0;
                             const bool pass0 = clears_rear(o, d, near0);
                             if (GUARD && near0) { unsure = true; searching = false; open = false; }
@@ -782,8 +809,10 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
             if (e != hipSuccess) return static_cast<int>(e);
             // the rays it listed (kolb_listed_body.hpp): the reference's arithmetic where a decision is too close to call;
             // workgroups beyond the list's length retire at once
+#if ZOIC_EXP_WHATIF != 3
             e = static_cast<hipError_t>(launch_kolb_listed(table, bokeh, sp, rp, rayBase + done, static_cast<uint32_t>(m), o, d_counters, redoCursor,
                                                            d_redoList, redoCount, grid, stream));
+#endif
         }
 #undef ZOIC_LAUNCH_POOL_BY_COUNT
 #undef ZOIC_LAUNCH_POOL

@@ -151,6 +151,13 @@ class ZoicFrame:
         return dict(device=info.device, peer_access_to_root=bool(info.peer_access_to_root), peer_access_from_root=bool(info.peer_access_from_root),
                     chunks=info.chunks, rays=info.rays, bytes_to_root=info.bytes_to_root)
 
+    def auto_layout(self):
+        """(layout FRAME_PAYLOAD_AUTO has chosen for the tables the frame holds: FRAME_PAYLOAD / FRAME_PAYLOAD_SPARSE, None while undecided;
+        the zero-weight fraction it measured, None while undecided) -- zoic_frame_auto_layout."""
+        z = C.c_double(-1.0)
+        r = self._lib.zoic_frame_auto_layout(self._h, C.byref(z))
+        return (None if r < 0 else int(r)), (None if z.value < 0 else z.value)
+
     def counters(self):
         c = _capi.Counters()
         self._check(self._lib.zoic_frame_get_counters(self._h, C.byref(c)))

@@ -80,7 +80,14 @@ class ShardedFrame:
         # ray and the compacted rows; rows of weight-0 rays arrive as zeros (their origin / direction, the reference's partial state
         # of the last try, and their try counts stay on the rank that traced them).  A chunk's size is then only known to its
         # sender: every round starts with the peers' live counts (one small message each), the root sizes its receives from them.
-        self.sparse = bool(sparse)
+        # sparse="auto": the layout is chosen from the camera -- the first gathered run is dense, the root then looks at the frame it holds
+        # and every later run ships sparse only if at least AUTO_SPARSE_ZERO_WEIGHT of the rays had weight 0 (C5: 79 % -> sparse, 4.5x fewer
+        # bytes into the root; C3: 0.07 % -> dense: the sparse layout's per-chunk count round and expansion pass cost more than its
+        # headers save -- bench.py measured 12.1 against 23.3 Grays/s on one GPU).  One 8-byte broadcast, once.
+        self.sparse_auto = sparse == "auto"
+        self.auto_decided = not self.sparse_auto
+        self.zero_weight_fraction = None      # what the root measured (auto mode; every rank holds it after the decision)
+        self.sparse = bool(sparse) and not self.sparse_auto
         self.root_bytes = 0          # bytes received by the root in the last run(gather=True)
         self.slabs = all_slabs(n_total, self.world, tile)
         if chunk_bytes is None:
@@ -139,7 +146,9 @@ class ShardedFrame:
                 if self.rank == self.dst:
                     if rec is not None:
                         pay = rec[:, :self.k]
-                        self.full[a:b].copy_(pay * (pay[:, 6:7] != 0))     # the root's own slab in the same convention
+                        # the root's own slab in the same convention: a weight-0 row is seven exact +0 (a product with the mask
+                        # would leave NaN for a NaN / Inf component of a dead ray's partial state and -0 for a negative one)
+                        self.full[a:b].copy_(torch.where(pay[:, 6:7] != 0, pay, torch.zeros_like(pay)))
                     peers = [r for r in range(self.world) if r != self.dst and k < len(self.chunks[r])]
                     counts = {r: torch.zeros(1, dtype=torch.int64, device=self.device) for r in peers}
                     for q in (dist.batch_isend_irecv([dist.P2POp(dist.irecv, counts[r], r) for r in peers]) if peers else []):
@@ -182,12 +191,36 @@ class ShardedFrame:
                 caller.wait_stream(cs)
         return self.full
 
+    AUTO_SPARSE_ZERO_WEIGHT = 0.25
+
+    def _decide_layout(self):
+        """sparse="auto", after the first dense gather: the root holds the whole frame -- its zero-weight fraction picks the layout of
+        every later run, for every rank (one broadcast of two numbers)."""
+        torch, dist = self.torch, self.dist
+        t = torch.zeros(2, dtype=torch.float64, device=self.device)
+        if self.rank == self.dst:
+            if self.cuda:
+                torch.cuda.current_stream(self.device).synchronize()
+            zero = float((self.full[:, 6] == 0).to(torch.float64).mean())
+            t[0], t[1] = zero, 1.0 if zero >= self.AUTO_SPARSE_ZERO_WEIGHT else 0.0
+        dist.broadcast(t, src=self.dst)
+        self.zero_weight_fraction, self.sparse = float(t[0].item()), bool(t[1].item() != 0.0)
+        self.auto_decided = True
+
     def run(self, gather=True):
         """Render this rank's slab chunk by chunk; with gather=True the payload of chunk k travels while chunk k+1 is
         traced.  Returns the root's full (n_total, 7) tensor (None on the other ranks, or when gather=False)."""
+        if gather and self.world > 1:
+            if not self.auto_decided:
+                full = self._run_dense(True)
+                self._decide_layout()
+                return full
+            if self.sparse:
+                return self._run_sparse()
+        return self._run_dense(gather)
+
+    def _run_dense(self, gather):
         import contextlib
-        if gather and self.sparse and self.world > 1:
-            return self._run_sparse()
         torch, dist = self.torch, self.dist
         mine = self.chunks[self.rank]
         pending = []
