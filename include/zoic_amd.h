@@ -46,7 +46,8 @@ extern "C" {
  *   5  round 6: zoic_camera_set_wait_mode (how a render thread waits for the resident kernel: spin / yield / sleep); a zoic_tile that
  *      outlives its camera is DETACHED by zoic_camera_destroy (every call but zoic_tile_destroy fails, the array getters return NULL)
  *      instead of dangling; zoic_tile_done restarts a resident kernel that retired under the poll; ZOIC_FRAME_PAYLOAD_AUTO +
- *      zoic_frame_auto_layout (the gather's layout chosen from the camera's dead-ray fraction).  Nothing of ABI 4 changed shape. */
+ *      zoic_frame_auto_layout (the gather's layout chosen from the camera's dead-ray fraction); zoic_create_rays_device_resident (device
+ *      buffers through the resident kernel, no launch).  Nothing of ABI 4 changed shape. */
 #define ZOIC_AMD_ABI_VERSION 5
 
 typedef enum zoic_status {
@@ -284,6 +285,15 @@ zoic_status zoic_tile_set_inputs(zoic_tile *tile, int inputs);
 float *zoic_tile_samples(zoic_tile *tile);   /* capacity x 4 floats: the same memory as zoic_tile_inputs */
 zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoic_camera_input *inputs, zoic_camera_output *outputs,
                                          uint64_t ray_index_base, uint16_t tid);
+/* The same resident kernel for a GPU consumer's mid-size batch: n <= ZOIC_RESIDENT_MAX_SAMPLES (sx, sy, lensx, lensy) samples in DEVICE memory
+ * -> n zoic_ray records in DEVICE memory, what zoic_create_rays_device(cam, n, d_samples, NULL, ray_index_base, d_rays, stream) writes, bit
+ * for bit, without a kernel launch: a launch-based call costs 52-76 us whatever it carries, this one ~20-30 us per
+ * 65536 samples.  NOT stream-ordered: d_samples must be complete when the call is made (synchronise the stream that produced them), the
+ * call returns when d_rays is complete and visible to any kernel launched afterwards.  Pieces of 65536 samples are served one after the
+ * other on the mailbox slot of `tid`: beyond a few hundred thousand samples zoic_create_rays_device's one launch is the faster call. */
+#define ZOIC_RESIDENT_MAX_SAMPLES 1048576u
+zoic_status zoic_create_rays_device_resident(zoic_camera *cam, uint32_t n, const float *d_samples, zoic_ray *d_rays, uint64_t ray_index_base,
+                                             uint16_t tid);
 /* camera_reverse_ray, zoic.cpp:1992-1995: the reference returns false and writes nothing; so does this (returns 0). */
 int zoic_camera_reverse_ray(const zoic_camera *cam, const zoic_vec3 *Po, float fov, float *Ps /* [2] */,
                             float *relative_time);

@@ -395,3 +395,124 @@ def test_tile_fuzz_random_cameras_hostile_samples_both_modes(gpu):
         assert c_ref == c_out, (p, fast, c_ref, c_out)
         cam.close()
     run()
+
+
+def test_a_tile_outliving_its_camera_is_detached_not_dangling(gpu):
+    """zoic_tile_destroy dereferenced tile->cam, so a tile destroyed (or garbage-collected) after its camera read freed
+    memory -- and locked a freed mutex with a submit pending.  zoic_camera_destroy now settles and DETACHES the tiles still alive: the
+    array getters return NULL, every call fails with INVALID_ARGUMENT, zoic_tile_destroy frees the handle.  (Through the raw C-ABI: the
+    Python mirror closes a camera's tiles before the camera.)"""
+    import ctypes as C
+    cam = camera("C2", PRECISION_FAST)
+    lib = cam._lib
+    a, _s, base = inputs_of("C2", 4096, 0.3)
+    h = C.c_void_p()
+    assert lib.zoic_tile_create(cam._h, 4096, 3, C.byref(h)) == 0
+    pin = C.cast(lib.zoic_tile_inputs(h), C.c_void_p).value
+    C.memmove(pin, a.ctypes.data, a.nbytes)
+    assert lib.zoic_tile_submit(h, 4096, base) == 0          # in flight while the camera goes
+    lib.zoic_camera_destroy(cam._h)
+    cam._h = None
+    assert not C.cast(lib.zoic_tile_inputs(h), C.c_void_p).value and not C.cast(lib.zoic_tile_outputs(h), C.c_void_p).value
+    assert lib.zoic_tile_capacity(h) == 0 and lib.zoic_tile_done(h) == 1
+    assert lib.zoic_tile_submit(h, 16, 0) == 1 and lib.zoic_tile_wait(h) == 1 and lib.zoic_tile_set_rows(h, 1) == 1      # ZOIC_ERR_INVALID_ARGUMENT
+    lib.zoic_tile_destroy(h)
+    # ... and the mirror's own order: ZoicCamera.close() closes the tiles, their numpy views are gone with them
+    cam = camera("C2", PRECISION_FAST)
+    t = cam.tile(1024, tid=1)
+    t.inputs[:1024] = a[:1024]
+    t.submit(1024, base)
+    cam.close()
+    assert t._h is None and t.inputs is None and t.outputs is None and t.samples is None and t.rays is None
+    t.close()
+
+
+def test_polling_done_without_wait_survives_the_kernels_retirement(gpu):
+    """zoic_tile_done only read the flags; a resident kernel that retired between the submit's look at `alive` and
+    the slot wave's look at the request line was never restarted, and a caller following the documented submit-then-poll pattern spun
+    for ever.  done() now restarts it.  The kernel retires after 1 ms without a call: sleeping 2-3 ms between tiles makes every submit
+    meet a retiring or retired kernel; the poll loop has no wait() in it."""
+    cam = camera("C2", PRECISION_FAST)
+    a, _s, base = inputs_of("C2", 4096, 0.3)
+    ref = cam.create_rays_arnold(a, ray_index_base=base)
+    tile = cam.tile(4096, tid=4)
+    tile.inputs[:4096] = a
+    for i in range(120):
+        time.sleep(0.0009 + 0.0001 * (i % 25))      # 0.9 ... 3.3 ms: around the kernel's 1 ms idle limit
+        tile.outputs[:] = np.float32(7.0)
+        tile.submit(4096, base)
+        t0 = time.time()
+        while not tile.done():
+            assert time.time() - t0 < 10.0, "zoic_tile_done never came true (tile %d)" % i
+        assert same_rows(tile.outputs[:4096], ref), i
+    tile.wait()
+    tile.close()
+    cam.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_wait_modes_give_the_same_rows(gpu, mode):
+    """zoic_camera_set_wait_mode: YIELD / SLEEP change how a render thread waits (sched_yield / 20 us sleeps after a short spin), nothing
+    else -- tiles from 24 threads (more than the box's CPU quota admits at once) and per-sample calls equal the spinning camera's."""
+    cam = camera("C3", PRECISION_FAST)
+    a, s, base = inputs_of("C3", 8192, 0.45)
+    ref = cam.create_rays_arnold(a, ray_index_base=base)
+    one = [cam.create_ray(*[float(v) for v in s[k]], tid=7) for k in range(8)]
+    cam.set_wait_mode(mode)
+    bad = []
+
+    def worker(tid):
+        t = cam.tile(8192, tid=tid)
+        t.inputs[:8192] = a
+        for _ in range(6):
+            t.submit(8192, base)
+            t.wait()
+            if not same_rows(t.outputs[:8192], ref):
+                bad.append(tid)
+        t.close()
+    th = [threading.Thread(target=worker, args=(tid,)) for tid in range(24)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not bad, bad
+    cam2 = camera("C3", PRECISION_FAST)      # a fresh camera: tid 7's stream starts where the first camera's did
+    cam2.set_wait_mode(mode)
+    again = [cam2.create_ray(*[float(v) for v in s[k]], tid=7) for k in range(8)]
+    for x, y in zip(one, again):
+        assert (x.dir.x, x.dir.y, x.dir.z, x.weight[0]) == (y.dir.x, y.dir.y, y.dir.z, y.weight[0]) or (x.dir.x != x.dir.x and y.dir.x != y.dir.x)
+    with pytest.raises(ZoicError):
+        cam.set_wait_mode(5)
+    cam.close()
+    cam2.close()
+
+
+@pytest.mark.parametrize("cfg,where", [("C1", 0.4), ("C2", 0.08), ("C3", 0.3), ("C4", 0.5), ("C5", 0.12)])
+@pytest.mark.parametrize("precision", [PRECISION_STRICT, PRECISION_FAST])
+def test_device_buffers_through_the_resident_kernel_equal_the_launch(gpu, cfg, where, precision):
+    """zoic_create_rays_device_resident -- samples and records in DEVICE memory served by the resident tile workers, no
+    launch -- writes the records of zoic_create_rays_device for the same samples and ray indices, bit for bit, for n in {1, 65, 4096,
+    65536, 200 003} (the last one crosses three 65536-sample pieces); nothing beyond record n is touched; counters count the rays once."""
+    import torch
+    cam = camera(cfg, precision)
+    n_max = 200_003
+    _a, s, base = inputs_of(cfg, n_max, where)
+    ds = torch.from_numpy(s).cuda()
+    ref = cam.create_rays(ds, ray_index_base=base)["rays"].clone()
+    torch.cuda.synchronize()
+    before = cam.counters()
+    done = 0
+    for n in (1, 65, 4096, 65536, n_max):
+        out = torch.full((n + 8, 8), 7.0, dtype=torch.float32, device="cuda")
+        got = cam.create_rays_resident(ds[:n], ray_index_base=base, out=out[:n], tid=13)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int32), ref[:n].view(torch.int32)), (cfg, precision, n)
+        assert bool((out[n:] == 7.0).all())
+        done += n
+    after = cam.counters()
+    if cfg != "C1":
+        assert after["succesRays"] + after["vignettedRays"] - before["succesRays"] - before["vignettedRays"] == done
+    # argument errors: host memory, a batch too large for this entry point
+    with pytest.raises(ZoicError):
+        cam._check(cam._lib.zoic_create_rays_device_resident(cam._h, 16, s.ctypes.data, out.data_ptr(), 0, 0))
+    with pytest.raises(ZoicError):
+        cam._check(cam._lib.zoic_create_rays_device_resident(cam._h, (1 << 20) + 1, ds.data_ptr(), out.data_ptr(), 0, 0))
+    cam.close()

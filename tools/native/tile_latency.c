@@ -4,7 +4,9 @@
  *   tile_latency <lens.dat> [threads=16] [samples_per_tile=65536] [tiles_per_thread=200] [precision 0|1|2] [lensModel 0|1] [mode]
  * mode: 0 = zoic_tile_submit + zoic_tile_wait on the tile's own arrays (zero copy), 1 = zoic_camera_create_rays_tile on malloc'd
  * arrays (staged through the slot's page-locked buffers), 2 = zoic_create_rays_arnold on malloc'd arrays (launch-based: the call the
- * tile server replaces), 3 = zoic_create_rays_arnold on page-locked arrays.
+ * tile server replaces), 3 = zoic_create_rays_arnold on page-locked arrays, 4 = zoic_create_rays_device_resident on DEVICE buffers (16-byte
+ * samples in, 32-byte records out: no PCIe rows, no launch), 5 = zoic_create_rays_device + a stream synchronise on the same device buffers
+ * (the launch-based call mode 4 replaces).  [rows] [ins] as zoic_tile_set_rows / _set_inputs (mode 0); [wait] = zoic_camera_set_wait_mode.
  * Prints one JSON line: p50 / p90 / p99 / mean microseconds per tile call, aggregate Mrays/s over the wall clock, and the PCIe
  * floor of a call (112 B per sample at 55 GB/s: 28 B in, 84 B out). */
 #define _GNU_SOURCE
@@ -17,6 +19,13 @@
 #include <time.h>
 
 #include "zoic_amd.h"
+
+/* modes 4 / 5 need device memory, which the C-ABI does not hand out (a GPU consumer owns its buffers): the three HIP entry points
+ * they need, declared by hand so that this file stays plain C for gcc (linked with -lamdhip64, which libzoic_amd.so loads anyway) */
+extern int hipMalloc(void **p, size_t bytes);
+extern int hipFree(void *p);
+extern int hipMemcpy(void *dst, const void *src, size_t bytes, int kind);   /* 1 = host to device, 2 = device to host */
+extern int hipStreamSynchronize(void *stream);
 
 static zoic_camera *cam;
 static int tiles = 200, mode = 0, rows = 0, ins = 0;   /* ins: 1 = 16-byte samples instead of AtCameraInput rows (mode 0 only) */
@@ -82,7 +91,11 @@ static void *worker(void *arg)
     zoic_tile *tile = NULL;
     zoic_camera_input *in = NULL;
     zoic_camera_output *out = NULL;
-    if (mode == 0) {
+    float *d_in = NULL; zoic_ray *d_out = NULL;
+    if (mode >= 4) {
+        in = malloc(sizeof(*in) * per_tile); out = malloc(sizeof(*out) * per_tile);
+        if (hipMalloc((void **)&d_in, 16u * (size_t)per_tile) != 0 || hipMalloc((void **)&d_out, sizeof(zoic_ray) * (size_t)per_tile) != 0) { fprintf(stderr, "hipMalloc failed\n"); exit(2); }
+    } else if (mode == 0) {
         if (zoic_tile_create(cam, per_tile, (uint16_t)tid, &tile) != ZOIC_OK) { fprintf(stderr, "tile: %s\n", zoic_last_error_string()); exit(2); }
         if (ins && zoic_tile_set_inputs(tile, ZOIC_TILE_INPUTS_SAMPLES) != ZOIC_OK) { fprintf(stderr, "tile inputs: %s\n", zoic_last_error_string()); exit(2); }
         if (rows && zoic_tile_set_rows(tile, ZOIC_TILE_ROWS_RAYS) != ZOIC_OK) { fprintf(stderr, "tile rows: %s\n", zoic_last_error_string()); exit(2); }
@@ -94,26 +107,31 @@ static void *worker(void *arg)
     }
     memset(out, 0, sizeof(*out) * per_tile);
     fill(in, 0, per_tile, &s, tid, 0);
+    if (mode >= 4 && hipMemcpy(d_in, in, 16u * (size_t)per_tile, 1) != 0) { fprintf(stderr, "hipMemcpy failed\n"); exit(2); }
     double sum = 0.0;
     const int warm = tiles > 20 ? 10 : 2;
     for (int k = -warm; k < tiles; ++k) {
         if (k == 0) { pthread_barrier_wait(&go); t_start[tid] = now_us(); }
         /* a fresh quarter of the inputs per tile (a renderer writes all of them; the generator here is slower than the GPU) */
-        fill(in, (size_t)((k + warm) & 3) * (per_tile / 4), per_tile / 4, &s, tid, k);
+        if (mode < 4) fill(in, (size_t)((k + warm) & 3) * (per_tile / 4), per_tile / 4, &s, tid, k);   /* (device buffers: a GPU producer made them) */
         const uint64_t base = ((uint64_t)tid << 40) + (uint64_t)(k + warm) * per_tile;
         const double t0 = now_us();
         zoic_status st;
         if (mode == 0) { st = zoic_tile_submit(tile, per_tile, base); if (st == ZOIC_OK) st = zoic_tile_wait(tile); }
         else if (mode == 1) st = zoic_camera_create_rays_tile(cam, per_tile, in, out, base, (uint16_t)tid);
+        else if (mode == 4) st = zoic_create_rays_device_resident(cam, per_tile, d_in, d_out, base, (uint16_t)tid);
+        else if (mode == 5) { st = zoic_create_rays_device(cam, per_tile, d_in, NULL, base, d_out, NULL); if (st == ZOIC_OK && hipStreamSynchronize(NULL) != 0) st = ZOIC_ERR_HIP; }
         else st = zoic_create_rays_arnold(cam, per_tile, in, out, base);
         if (st != ZOIC_OK) { fprintf(stderr, "tile call: %s\n", zoic_last_error_string()); exit(2); }
         if (k >= 0) lat[(size_t)tid * tiles + k] = now_us() - t0;
-        if (rows) { const zoic_ray *r = (const zoic_ray *)out; sum += r[(size_t)(k + warm) % per_tile].dz + r[per_tile - 1].weight; }
+        if (mode >= 4) { if (k == tiles - 1) { zoic_ray r; hipMemcpy(&r, d_out + per_tile - 1, sizeof r, 2); sum += r.dz + r.weight; } }
+        else if (rows) { const zoic_ray *r = (const zoic_ray *)out; sum += r[(size_t)(k + warm) % per_tile].dz + r[per_tile - 1].weight; }
         else sum += out[(size_t)(k + warm) % per_tile].dir.z + out[per_tile - 1].weight[0];
     }
     t_end[tid] = now_us();
     sums[tid] = sum;
-    if (tile) zoic_tile_destroy(tile);
+    if (mode >= 4) { hipFree(d_in); hipFree(d_out); free(in); free(out); }
+    else if (tile) zoic_tile_destroy(tile);
     else if (mode == 3) { zoic_host_free(in); zoic_host_free(out); }
     else { free(in); free(out); }
     return NULL;
@@ -121,7 +139,7 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: tile_latency lens.dat [threads] [samples_per_tile] [tiles_per_thread] [precision] [lensModel] [mode] [rows] [ins]\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: tile_latency lens.dat [threads] [samples_per_tile] [tiles_per_thread] [precision] [lensModel] [mode] [rows] [ins] [wait]\n"); return 1; }
     const int threads = argc > 2 ? atoi(argv[2]) : 16;
     if (argc > 3) per_tile = (uint32_t)atoi(argv[3]);
     if (argc > 4) tiles = atoi(argv[4]);
@@ -129,12 +147,15 @@ int main(int argc, char **argv)
     if (argc > 7) mode = atoi(argv[7]);
     if (argc > 8) rows = atoi(argv[8]);
     if (argc > 9) ins = atoi(argv[9]);
-    if (threads < 1 || threads > 256 || per_tile < 4 || (mode <= 0 && per_tile > ZOIC_TILE_MAX_SAMPLES) || tiles < 1) { fprintf(stderr, "bad arguments\n"); return 1; }
+    const int waitMode = argc > 10 ? atoi(argv[10]) : 0;
+    if (mode >= 4) ins = 1;   /* fill() writes 16-byte samples */
+    if (threads < 1 || threads > 256 || per_tile < 4 || (mode <= 0 && per_tile > ZOIC_TILE_MAX_SAMPLES) || (mode == 4 && per_tile > ZOIC_RESIDENT_MAX_SAMPLES) || tiles < 1) { fprintf(stderr, "bad arguments\n"); return 1; }
     zoic_params p;
     zoic_params_default(&p);
     p.lensDataPath = argv[1]; p.lensModel = model; p.focalLength = 5.0f; p.fStop = 2.0f;
     if (zoic_camera_create(0, &cam) != ZOIC_OK || zoic_camera_update(cam, &p) != ZOIC_OK ||
         zoic_camera_set_precision(cam, (zoic_precision)precision) != ZOIC_OK) { fprintf(stderr, "camera: %s\n", zoic_last_error_string()); return 2; }
+    if (zoic_camera_set_wait_mode(cam, (zoic_wait_mode)waitMode) != ZOIC_OK) { fprintf(stderr, "wait mode: %s\n", zoic_last_error_string()); return 2; }
     const int node = pin_to_gpu_node();   /* inherited by the worker threads */
     lat = malloc(sizeof(double) * (size_t)threads * tiles);
     pthread_barrier_init(&go, NULL, (unsigned)threads);
@@ -149,10 +170,10 @@ int main(int argc, char **argv)
     qsort(lat, n, sizeof(double), cmp);
     zoic_counters c;
     zoic_camera_get_counters(cam, &c);
-    const double floor_us = 112.0 * per_tile / 55e9 * 1e6;
-    printf("{\"mode\": %d, \"threads\": %d, \"samples_per_tile\": %u, \"tiles_per_thread\": %d, \"precision\": %d, \"lensModel\": %d, \"p50_us\": %.2f, "
+    const double floor_us = mode >= 4 ? 0.0 : 112.0 * per_tile / 55e9 * 1e6;
+    printf("{\"mode\": %d, \"wait_mode\": %d, \"threads\": %d, \"samples_per_tile\": %u, \"tiles_per_thread\": %d, \"precision\": %d, \"lensModel\": %d, \"p50_us\": %.2f, "
            "\"p90_us\": %.2f, \"p99_us\": %.2f, \"mean_us\": %.2f, \"mrays_s\": %.1f, \"pcie_floor_us\": %.2f, \"rays_counted\": %llu, \"checksum\": %.6g, \"numa_node\": %d}\n",
-           mode, threads, per_tile, tiles, precision, model, lat[n / 2], lat[n * 9 / 10], lat[n * 99 / 100], mean / n,
+           mode, waitMode, threads, per_tile, tiles, precision, model, lat[n / 2], lat[n * 9 / 10], lat[n * 99 / 100], mean / n,
            (double)n * per_tile / (last - first), floor_us, (unsigned long long)(c.succesRays + c.vignettedRays), check, node);
     zoic_camera_destroy(cam);
     return 0;

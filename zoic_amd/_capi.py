@@ -102,6 +102,7 @@ SYMBOLS = {
     "zoic_tile_submit": (C.c_int, [_vp, _u32, _u64]),
     "zoic_tile_wait": (C.c_int, [_vp]),
     "zoic_tile_done": (C.c_int, [_vp]),
+    "zoic_create_rays_device_resident": (C.c_int, [_vp, C.c_uint32, _vp, _vp, C.c_uint64, C.c_uint16]),
     "zoic_tile_set_rows": (C.c_int, [_vp, C.c_int]),
     "zoic_tile_rays": (C.c_void_p, [_vp]),
     "zoic_tile_set_inputs": (C.c_int, [_vp, C.c_int]),

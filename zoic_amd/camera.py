@@ -297,6 +297,22 @@ class ZoicCamera:
         self._check(self._lib.zoic_create_rays_device(self._h, n, d_samples, d_rng, int(ray_index_base), d_rays,
                                                       C.c_void_p(stream)))
 
+    def create_rays_resident(self, samples, ray_index_base=0, out=None, tid=0):
+        """(n, 4) float32 samples on the camera's device -> (n, 8) float32 zoic_ray records on the device through the RESIDENT kernel
+        (zoic_create_rays_device_resident): no launch, not stream-ordered -- the current stream is synchronised first (the samples must
+        be complete), the records are complete on return.  The bits of create_rays(samples, ray_index_base=...)."""
+        import torch
+        if samples.dtype != torch.float32 or samples.dim() != 2 or samples.shape[1] != 4 or not samples.is_contiguous():
+            raise ValueError("samples must be a contiguous (n, 4) float32 device tensor")
+        n = samples.shape[0]
+        if out is None:
+            out = torch.empty((n, 8), dtype=torch.float32, device=samples.device)
+        if tuple(out.shape) != (n, 8) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != samples.device:
+            raise ValueError("out must be a contiguous (n, 8) float32 tensor on the samples' device")
+        torch.cuda.current_stream(samples.device).synchronize()
+        self._check(self._lib.zoic_create_rays_device_resident(self._h, n, samples.data_ptr(), out.data_ptr(), int(ray_index_base), int(tid) & 0xFFFF))
+        return out
+
     def create_ray(self, sx, sy, lensx, lensy, tid=0):
         """The per-sample camera_create_ray(node, input, output, tid) signature (one AtCameraInput in, one AtCameraOutput out)."""
         i = _capi.CameraInput(sx, sy, 0.0, 0.0, lensx, lensy, 0.0)

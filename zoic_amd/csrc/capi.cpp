@@ -1596,6 +1596,42 @@ zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoi
     return ZOIC_OK;
 }
 
+zoic_status zoic_create_rays_device_resident(zoic_camera *cam, uint32_t n, const float *d_samples, zoic_ray *d_rays, uint64_t ray_index_base, uint16_t tid)
+{
+    // zoic_create_rays_device costs a launch (52-76 us) whatever it carries.  The resident tile workers read a tile's samples
+    // and write its records through plain addresses at system scope: device memory serves as well as mapped host memory, so a GPU
+    // consumer's batch is a tile request with 16-byte samples in and 32-byte records out -- the layouts of zoic_create_rays_device.
+    if (zoic_status s = check_tile_call(cam)) return s;
+    if (n == 0u) return ZOIC_OK;
+    if (!d_samples || !d_rays) return fail(ZOIC_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > ZOIC_RESIDENT_MAX_SAMPLES) return fail(ZOIC_ERR_INVALID_ARGUMENT, "n exceeds ZOIC_RESIDENT_MAX_SAMPLES: zoic_create_rays_device is the call for large batches");
+    if ((reinterpret_cast<uintptr_t>(d_samples) & 15u) || (reinterpret_cast<uintptr_t>(d_rays) & 15u)) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_samples and d_rays must be 16-byte aligned");
+    DeviceGuard guard(cam->device);
+    ZOIC_HIP(guard.error());
+    {
+        // memory of the camera's device (a host pointer, or another device's memory without peer mapping, would fault inside a kernel
+        // that serves every render thread of this camera)
+        hipPointerAttribute_t ai, ao;
+        const bool ok = hipPointerGetAttributes(&ai, d_samples) == hipSuccess && ai.type == hipMemoryTypeDevice && ai.device == cam->device &&
+                        hipPointerGetAttributes(&ao, d_rays) == hipSuccess && ao.type == hipMemoryTypeDevice && ao.device == cam->device;
+        (void)hipGetLastError();
+        if (!ok) return fail(ZOIC_ERR_INVALID_ARGUMENT, "d_samples / d_rays must be device memory of the camera's device");
+    }
+    Mailbox &M = cam->mail;
+    const unsigned slot = tid % kMailSlots;
+    std::lock_guard<std::mutex> slotLock(M.slotM[slot]);
+    if (zoic_status s = tile_settle_locked(cam, slot)) return s;
+    const uint64_t dIn = reinterpret_cast<uint64_t>(d_samples), dOut = reinterpret_cast<uint64_t>(d_rays);
+    uint32_t seq = 0;
+    for (uint32_t off = 0; off < n; off += kTileMaxSamples) {
+        const uint32_t m = std::min<uint32_t>(kTileMaxSamples, n - off);
+        if (zoic_status s = tile_post_locked(cam, slot, m, dIn + static_cast<uint64_t>(off) * 16u, dOut + static_cast<uint64_t>(off) * sizeof(zoic_ray), ray_index_base + off, &seq,
+                                             ZOIC_TILE_ROWS_RAYS | (ZOIC_TILE_INPUTS_SAMPLES << 1))) return s;
+        if (zoic_status s = tile_settle_locked(cam, slot)) return s;
+    }
+    return ZOIC_OK;
+}
+
 int zoic_camera_reverse_ray(const zoic_camera *cam, const zoic_vec3 *Po, float fov, float *Ps, float *relative_time)
 {
     // camera_reverse_ray, zoic.cpp:1992-1995: `return false;` -- nothing is written

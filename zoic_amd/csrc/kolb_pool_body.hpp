@@ -778,7 +778,7 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
         unsigned int *d_clearCursor = d_cursorPair + ((*parity & 1u) ^ 1u) * kCursorBlockWords;
         *parity ^= 1u;
         const unsigned grid = persistent_grid(m, kWavesPerBlock);
-        const WorkGrain grain = work_grain(m, mode == 0 ? 256u : 512u);
+        const WorkGrain grain = work_grain(m, mode == 0 ? 256u : 512u, true);
         const uint32_t chunkRays = grain.chunkRays, chunksPerPart = grain.chunksPerPart;
         RayRecord *o = out + done;
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
