@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzoic_amd.so")
-SOURCES = ["capi.cpp", "frame.cpp", "lens_system.cpp", "kernels.hip", "kolb_pool.hip", "kolb_pool_dead.hip", "kolb_listed.hip", "thin_refill.hip", "bokeh_cdf.hip", "mailbox.hip", "lut_build.hip"]
+SOURCES = ["capi.cpp", "frame.cpp", "lens_system.cpp", "kernels.hip", "kolb_pool.hip", "kolb_pool_dead.hip", "kolb_pool_two.hip", "kolb_listed.hip", "thin_refill.hip", "bokeh_cdf.hip", "mailbox.hip", "lut_build.hip"]
 # every header of csrc/ is a dependency of every object (a hand-kept list went stale twice: exact_math.hpp, kolb_refill_body.hpp)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(ROOT, "include", "zoic_amd.h")]
 

@@ -45,6 +45,14 @@
                             // 4 = finish_dead_ray does not re-read its sample
 #endif
 
+#ifndef ZOIC_TWO_LEVEL_SEARCH
+#define ZOIC_TWO_LEVEL_SEARCH 3   // draws per lane per round of the TWO-LEVEL retry search (DEAD kernels, disk sampler, cameras with KolbTable::twoLevel): a draw is
+                                  // only evaluated (disk mapping, direction, interface 0) when a per-ray bound cannot reject it.  0 compiles it out.
+                                  // [MI355X, profiles/ab_r06/ab_two_level.log] C2 decision-safe +3.9 % (3 draws; 2 draws +1.3 %), STRICT +2.4 %; C5 -2.5 % when forced on
+                                  // (2.8 % of its draws are rejectable) -- hence per camera.
+#endif
+constexpr int kTwoLevelDraws = ZOIC_TWO_LEVEL_SEARCH;
+
 namespace zoic {
 
 // Kernel arguments that only rare paths read (chunk claim, first retry, work-list flush, exit) are fetched from the kernarg
@@ -82,14 +90,15 @@ constexpr uint32_t kRetryDeadBit = 0x40000000u;   // lutMiss: bit 0 LUT miss, bi
 
 // Per-ray constants of camera_create_ray (zoic.cpp:1853-1855, 1891-1911): the sensor point, the exit-pupil LUT's scale and
 // translation, the (parabola) sine / cosine of the pupil rotation -- shared by phase A of the pass loop and by finish_dead_ray.  flags: bit 0 = outside the LUT (fenced UB), kRetryDeadBit = no retry of this ray can reach the rear element.
-struct RaySetup { float o0x, o0y, maxScale, translation, sn, cs; uint32_t flags; bool dead, lutEdge; };
-template <bool STRICT>
+// rminq (two-level retry search): a RETRY whose unit-square draw has max(|2u-1|, |2v-1|) < rminq / 256 cannot reach the rear element (0: no bound)
+struct RaySetup { float o0x, o0y, maxScale, translation, sn, cs; uint32_t flags; bool dead, lutEdge; uint32_t rminq; };
+template <bool STRICT, bool RMIN = false>   // RMIN: also the per-draw reject bound of the two-level retry search (kolb_pool_two.hip's kernels)
 __device__ __forceinline__ RaySetup setup_ray(const KolbTable &T, const float2 *lutLds, float sx, float sy)
 {
     RaySetup r;
     r.o0x = sx * T.halfSensor;  // zoic.cpp:1853-1854
     r.o0y = sy * T.halfSensor;
-    r.maxScale = 0.0f; r.translation = 0.0f; r.sn = 0.0f; r.cs = 1.0f; r.flags = 0u; r.dead = false; r.lutEdge = false;
+    r.maxScale = 0.0f; r.translation = 0.0f; r.sn = 0.0f; r.cs = 1.0f; r.flags = 0u; r.dead = false; r.lutEdge = false; r.rminq = 0u;
     if (T.useLUT) {            // zoic.cpp:1891-1911: per-sample constants of the exit-pupil transform
         float dist;
         if constexpr (STRICT) dist = fabsf(ZOIC_SQRT_RN(r.o0x * r.o0x + r.o0y * r.o0y));
@@ -121,6 +130,16 @@ __device__ __forceinline__ RaySetup setup_ray(const KolbTable &T, const float2 *
                 // |d.xy| of any retry <= |rotated, translated lens point| + |o.xy|: below retryMaxD the opposite cap is out of reach
                 const float dxyMax = fabsf(r.maxScale) * k + fabsf(r.translation) * 1.4158f + dist;
                 if (ccx * ccx + ccy * ccy > reach * reach && dxyMax <= T.retryMaxD) r.flags |= kRetryDeadBit;
+                // The same bound per DRAW (the two-level retry search: cameras with KolbTable::twoLevel run kernels compiled with it).  A retry's lens point lies within |maxScale| k rho of the doubly translated centroid Q, rho =
+                // max(|2u-1|, |2v-1|) (the concentric mapping's radius; k covers the parabola pair's 1.0011 twice), and can only pass
+                // interface 0 from inside the disk of radius `pass` around cc: a draw with |Q - cc| - |maxScale| k rho > pass is rejected
+                // whatever its angle.  rminq / 256 <= that rho bound, rounded DOWN, 1 % + 1e-4 of margin as above; disk sampler only.
+                if (RMIN && dxyMax <= T.retryMaxD) {
+                    const float pass = (T.retryRho0 + dist * T.retrySpread) * 1.01f + 1.0e-4f;
+                    const float gap = fsqrt_fast(ccx * ccx + ccy * ccy) * 0.999f - pass;
+                    const float rm = gap * frcp_fast(fabsf(r.maxScale) * k * 1.001f + 1.0e-30f);
+                    r.rminq = rm > 0.0f ? static_cast<uint32_t>(fminf(rm, 1.0f) * 255.0f) : 0u;
+                }
             }
         }
     }
@@ -267,11 +286,13 @@ constexpr uint32_t kShortList = 1u << 17;
 // IMAGE: the bokeh image is on AND its cell records are in LDS (tables.hpp; images up to 2048 rows x 4096 columns): every
 // lens sample is one ds_read_b128 + one global_load_dwordx4.  IMAGE = false covers the concentric-disk sampler and images
 // without records (16-ary pyramid / reference search through lens_sample's run-time branch).
-template <bool STRICT, int NS, bool GUARD, bool DEAD, bool IMAGE>
+// TWO: the two-level retry search (kTwoLevelDraws; kolb_pool_two.hip: DEAD kernels of the disk sampler, for cameras with KolbTable::twoLevel).
+template <bool STRICT, int NS, bool GUARD, bool DEAD, bool IMAGE, bool TWO = false>
 __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTables &B, const float4 *__restrict__ samples,
                                                uint32_t n, RayRecord *__restrict__ out, uint32_t ldsWords, uint32_t minSearching)
 {
     static_assert(!(GUARD && STRICT), "GUARD is a FAST mode");
+    static_assert(!TWO || (DEAD && !IMAGE && kTwoLevelDraws > 0), "the two-level search belongs to the DEAD kernels of the disk sampler");
     constexpr bool DEFER = GUARD || DEAD;   // rays may leave the pass loop unfinished: TIR bumps are tallied per ray
     constexpr bool PROBE = IMAGE && (!STRICT || ZOIC_POOL_PROBE_STRICT != 0);   // the next batch's first lens sample is requested a pass ahead
     constexpr uint32_t kOut = static_cast<uint32_t>(kMaxTries) + 1u;   // tries of a ray that ran out (zoic.cpp:1927: tries <= 25)
@@ -367,6 +388,8 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         bool active, dead, unsure = false;
         uint32_t idx, tries, lutMiss;   // lutMiss: bit 0 outside the LUT, bits 1.. the TIR tally, kRetryDeadBit
         float o0x, o0y, maxScale, translation, sn, cs;
+        uint32_t rminq = 0u;   // two-level search: the ray's per-draw reject bound (setup_ray)
+        (void)rminq;
         Rng rng{1, 2, 3, 4};
         V3 o, d{0.0f, 0.0f, 1.0f};
         bool cand = false, finiteSample = true, searching;
@@ -387,9 +410,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             // phase A: set 64 fresh rays up and run the search's FIRST step for all of them (zoic.cpp:1853-1925)
             active = lane < cnt1;
             idx = base1 + lane;
-                const RaySetup rs = setup_ray<STRICT>(T, lutLds, s1.x, s1.y);
+                const RaySetup rs = setup_ray<STRICT, TWO>(T, lutLds, s1.x, s1.y);
             o0x = rs.o0x; o0y = rs.o0y; maxScale = rs.maxScale; translation = rs.translation; sn = rs.sn; cs = rs.cs;
-            lutMiss = rs.flags; dead = rs.dead;
+            lutMiss = rs.flags; dead = rs.dead; rminq = rs.rminq;
             if constexpr (GUARD) unsure = active && T.useLUT && rs.lutEdge;
                 ZOIC_MARK(1)   // setup_ray
             tries = 0;
@@ -457,6 +480,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             tries = (packed >> kPoolTriesShift) & 31u;
             dead = (packed & kPoolDeadBit) != 0u;
             lutMiss = (packed & 0x7fu) | ((packed & kPoolRetryDeadBit) ? kRetryDeadBit : 0u);
+            if constexpr (TWO) rminq = (packed >> 16) & 0xffu;
             o = V3{o0x, o0y, T.originShift};
             searching = active;
         }
@@ -519,6 +543,8 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                         }
                     }
                 } else {
+                if constexpr (TWO) { /* handled below, wave-wide */ } else
+                {
                 const float u = rng_unit(xor128(rng));   // zoic.cpp:1930
                 const float v = rng_unit(xor128(rng));
                 ++tries;
@@ -528,6 +554,38 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 if (GUARD && near0) { unsure = true; searching = false; }
                 else if (pass0) { cand = true; searching = false; }
                 else if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
+                }
+                }
+            }
+            if constexpr (TWO) {
+                // Two levels.  Level 1: a lane draws -- tries and its retry stream advance exactly as in the reference's loop --
+                // until it holds a draw the per-ray bound cannot reject (or its last try, whose state the ray hands out), at most
+                // kTwoLevelDraws draws per round: ~25 instructions a draw.  Level 2: the disk mapping, the direction and the interface-0
+                // test, once per round, for the lanes that hold one: ~70.  A draw rejected at level 1 bumps no counter and leaves (o, d)
+                // untouched, like a clip at interface 0 (which is what it would have been).  A draw at the disk's centre (rho = 0: the
+                // reference's 0/0 -> NaN ray, which passes everything) is never rejected here.
+                bool pending = false;
+                float pu = 0.0f, pv = 0.0f;
+                const float rminf = static_cast<float>(rminq) * (1.0f / 256.0f);
+#pragma unroll
+                for (int k = 0; k < kTwoLevelDraws; ++k) {
+                    if (k > 0 && __ballot(searching && !pending) == 0ull) break;
+                    if (searching && !pending) {
+                        pu = rng_unit(xor128(rng));   // zoic.cpp:1930
+                        pv = rng_unit(xor128(rng));
+                        ++tries;
+                        const float rho = fmaxf(fabsf(ffma(2.0f, pu, -1.0f)), fabsf(ffma(2.0f, pv, -1.0f)));
+                        const bool hopeless = (rho < rminf) & (rho > 0.0f);
+                        pending = !hopeless | (tries > static_cast<uint32_t>(kMaxTries));
+                    }
+                }
+                if (searching && pending) {
+                    d = retry_direction(T, sample_lens(pu, pv), o0x, o0y, maxScale, translation, sn, cs);   // zoic.cpp:1932-1943: BOTH components translated
+                    bool near0;
+                    const bool pass0 = clears_rear(o, d, near0);
+                    if (GUARD && near0) { unsure = true; searching = false; }
+                    else if (pass0) { cand = true; searching = false; }
+                    else if (tries > static_cast<uint32_t>(kMaxTries)) searching = false;   // out of tries at interface 0
                 }
             }
         }
@@ -664,8 +722,9 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             if (m != 0ull) {
                 if (keep) {
                     const uint32_t slot = poolCnt + mask_rank(m);
-                    const uint32_t packed = (lutMiss & 0x7fu) | (tries << kPoolTriesShift) | (dead ? kPoolDeadBit : 0u) |
-                                            ((lutMiss & kRetryDeadBit) ? kPoolRetryDeadBit : 0u);
+                    uint32_t packed = (lutMiss & 0x7fu) | (tries << kPoolTriesShift) | (dead ? kPoolDeadBit : 0u) |
+                                      ((lutMiss & kRetryDeadBit) ? kPoolRetryDeadBit : 0u);
+                    if constexpr (TWO) packed |= rminq << 16;
                     pool0[slot] = make_float4(__builtin_bit_cast(float, idx), o0x, o0y, __builtin_bit_cast(float, packed));
 #if ZOIC_POOL_SLIM
                     pool1[slot] = make_float2(sn, cs);
@@ -745,10 +804,10 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
         uint32_t ldsWords, uint32_t chunkRays, uint32_t chunksPerPart, uint32_t minSearching, uint32_t *__restrict__ redoList,             \
         unsigned int *__restrict__ redoCount, unsigned int *__restrict__ clearCursor
 #define ZOIC_POOL_KERNEL(NAME_, ATTR_, STRICT_, GUARD_)                                                                        \
-    template <int NS, bool DEAD, bool IMAGE>                                                                                 \
+    template <int NS, bool DEAD, bool IMAGE, bool TWO = false>                                                               \
     __global__ __launch_bounds__(kRefillBlock) ATTR_ void NAME_(ZOIC_POOL_PARAMS)                                             \
     {                                                                                                                        \
-        kolb_pool_body<STRICT_, NS, GUARD_, DEAD, IMAGE>(T, B, samples, n, out, ldsWords, minSearching);                      \
+        kolb_pool_body<STRICT_, NS, GUARD_, DEAD, IMAGE, TWO>(T, B, samples, n, out, ldsWords, minSearching);                 \
     }
 ZOIC_POOL_KERNEL(kolb_pool_strict_kernel, ZOIC_POOL_ATTR_STRICT, true, false)          // STRICT, whole batch
 ZOIC_POOL_KERNEL(kolb_pool_fast_kernel, ZOIC_POOL_ATTR_FAST, false, false)             // FAST unchecked
@@ -762,7 +821,7 @@ int launch_kolb_listed(const KolbTable &table, const BokehTables &bokeh, const f
 
 // mode: 0 = STRICT, 1 = FAST decision-safe, 2 = FAST unchecked.  d_scratch: the work list of mode 1 (kolb_scratch_dwords():
 // one dword per sample of a launch)
-template <bool DEAD, bool IMAGE>
+template <bool DEAD, bool IMAGE, bool TWO = false>
 int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, const float *d_samples, const uint32_t *d_rng,
                           uint64_t rayBase, uint64_t n, RayRecord *out, DeviceCounters *d_counters, unsigned int *d_cursorPair, unsigned *parity,
                           int mode, uint32_t *d_scratch, void *stream)
@@ -778,7 +837,7 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
         unsigned int *d_clearCursor = d_cursorPair + ((*parity & 1u) ^ 1u) * kCursorBlockWords;
         *parity ^= 1u;
         const unsigned grid = persistent_grid(m, kWavesPerBlock);
-        const WorkGrain grain = work_grain(m, mode == 0 ? 256u : 512u, true);
+        const WorkGrain grain = work_grain(m, mode == 0 ? 256u : 512u);
         const uint32_t chunkRays = grain.chunkRays, chunksPerPart = grain.chunksPerPart;
         RayRecord *o = out + done;
         const float4 *sp = reinterpret_cast<const float4 *>(d_samples) + done;
@@ -789,7 +848,7 @@ int launch_kolb_pool_impl(const KolbTable &table, const BokehTables &bokeh, cons
         };
         unsigned int *redoCount = d_workCursor + kRedoCountOffset, *redoCursor = d_workCursor + kRedoCursorOffset;
 #define ZOIC_LAUNCH_POOL(KERNEL_, NS_, CURSOR_, GUARD_)                                                                          \
-    hipLaunchKernelGGL((KERNEL_<NS_, DEAD, IMAGE>), dim3(grid), dim3(kRefillBlock), lds_bytes(GUARD_), st, table, bokeh, sp, rp, rayBase + done, \
+    hipLaunchKernelGGL((KERNEL_<NS_, DEAD, IMAGE, TWO>), dim3(grid), dim3(kRefillBlock), lds_bytes(GUARD_), st, table, bokeh, sp, rp, rayBase + done, \
                        static_cast<uint32_t>(m), o, d_counters, CURSOR_, ldsWords, chunkRays, chunksPerPart, kMinSearching, d_redoList, redoCount, d_clearCursor)
 #define ZOIC_LAUNCH_POOL_BY_COUNT(KERNEL_, CURSOR_, GUARD_)                                                                      \
     switch (table.lensCount) {  /* unrolled instantiations for the interface counts of real prescriptions */                   \

@@ -90,6 +90,9 @@ struct KolbTable {
     float retryMaxD;      // the bounds above hold for hits on the VERTEX-side cap of the rear sphere; the root the reference takes
                           // (zoic.cpp:986: ONE signed root, t < 0 never rejected) can only land on the opposite |xy| <= a cap
                           // when |d.xy| / dirZ > sqrt(R^2 - a^2) / a: rays with |d.xy| above retryMaxD are never classified
+    int32_t twoLevel;     // the retry search rejects draws per ray before evaluating them (kolb_pool_body.hpp kTwoLevelDraws): set by the host for cameras
+                          // where enough of the sensor's retries are rejectable that way (the TESSAR at 10 cm: 58 % of the draws; the wide-open
+                          // PETZVAL: 3 % -- there the bound's instructions cost more than they save)
     float retryLensK;     // bound of |lens sample| x the parabola rotation's 1.0011: 1.0023 for the disk mapping; for a bokeh image
                           // what zoic.cpp:441,466 can return -- the centring swaps width and height, so an image that is not
                           // square samples far outside the unit square (2 x 7 pixels: x in [-3, -2])
