@@ -596,9 +596,11 @@ def tile_server_entry():
             ("tile_4_threads_x_4096", ["4", "4096", "600", "1", "1", "0"]), ("tile_1_thread_x_4096", ["1", "4096", "1000", "1", "1", "0"]),
             ("tile_1_thread_x_256", ["1", "256", "1000", "1", "1", "0"]), ("tile_thin_lens_1_thread_x_4096", ["1", "4096", "1000", "1", "0", "0"]),
             ("launch_16_threads_x_65536", ["16", "65536", "30", "1", "1", "3"]), ("launch_1_thread_x_4096", ["1", "4096", "300", "1", "1", "3"]),
-            # more render threads than this box's CPU quota admits at once, spinning (default) and with yielding waits (zoic_camera_set_wait_mode)
-            ("tile_64_threads_x_4096_spin", ["64", "4096", "150", "1", "1", "0", "0", "0", "0"]), ("tile_64_threads_x_4096_yield", ["64", "4096", "150", "1", "1", "0", "0", "0", "1"]),
-            ("tile_128_threads_x_4096_yield", ["128", "4096", "80", "1", "1", "0", "0", "0", "1"]),
+            # more render threads than this box's CPU quota admits at once: spinning (the default) against sleeping waits (zoic_camera_set_wait_mode;
+            # under a quota every thread has a core, so yielding spins all the same: profiles/ab_r06/tile_threads_wait_modes.txt)
+            ("tile_64_threads_x_4096_spin", ["64", "4096", "150", "1", "1", "0", "0", "0", "0"]), ("tile_64_threads_x_4096_sleep", ["64", "4096", "150", "1", "1", "0", "0", "0", "2"]),
+            ("tile_128_threads_x_4096_sleep", ["128", "4096", "80", "1", "1", "0", "0", "0", "2"]),
+            ("tile_rays_64_threads_x_65536_sleep", ["64", "65536", "20", "1", "1", "0", "1", "1", "2"]),
             # DEVICE buffers through the resident kernel (zoic_create_rays_device_resident: 16-byte samples in, 32-byte records out, no launch, no
             # PCIe rows) beside the launch-based device call + stream synchronise it replaces
             ("device_tile_1_thread_x_65536", ["1", "65536", "500", "1", "1", "4"]), ("device_tile_1_thread_x_4096", ["1", "4096", "1000", "1", "1", "4"]),

@@ -188,10 +188,11 @@ zoic_status zoic_camera_set_frame_aspect(zoic_camera *cam, float max_abs_sy);
 /* How a render thread waits for the camera's RESIDENT kernel (zoic_camera_create_ray, zoic_tile_wait, zoic_camera_create_rays_tile).
  *   ZOIC_WAIT_SPIN   (default) a `pause` loop on the reply / the tile's flags: lowest latency, one core per waiting thread.  Right when
  *                    the render threads have a core each.
- *   ZOIC_WAIT_YIELD  spins for ~2 us, then sched_yield() between polls: for hosts with more render threads than cores (or a CPU quota
- *                    below the thread count), where spinning threads are descheduled for whole scheduler periods while the thread that
- *                    would have posted the next tile waits for a core (csrc/capi.cpp mailbox_await; DESIGN 1.1 "many render threads").
+ *   ZOIC_WAIT_YIELD  spins for ~2 us, then sched_yield() between polls: for hosts with more render threads than CORES.  (Under a CPU quota
+ *                    with idle cores -- a container -- sched_yield returns at once and burns quota like the spin: use ZOIC_WAIT_SLEEP there.)
  *   ZOIC_WAIT_SLEEP  spins for ~2 us, then sleeps 20 us between polls: a waiting thread costs next to nothing; +10-20 us per call.
+ *                    [MI355X box, 16-CPU quota, 4096-sample tiles] 64 threads: 573 Mrays/s, p99 0.58 ms (spinning: 240 Mrays/s, p99 10 ms;
+ *                    16 threads spinning: 490); 128 threads: 575 Mrays/s (profiles/ab_r06/tile_threads_wait_modes.txt).
  * Any thread, any time; takes effect at the next wait. */
 typedef enum zoic_wait_mode { ZOIC_WAIT_SPIN = 0, ZOIC_WAIT_YIELD = 1, ZOIC_WAIT_SLEEP = 2 } zoic_wait_mode;
 zoic_status zoic_camera_set_wait_mode(zoic_camera *cam, zoic_wait_mode mode);
