@@ -798,7 +798,7 @@ def main():
                             compute_ms=strong["compute_ms"], root_ingest_gb_s=strong["root_ingest_gb_s"], root_ingest_frac=strong["root_ingest_frac"],
                             bit_identical_to_single_gpu=strong.get("bit_identical_to_single_gpu"), sub_launches_per_slab=strong["sub_launches_per_slab"],
                             chunk_mb=strong["chunk_mb"])
-                for k in ("root_bytes", "with_sparse_gather", "sparse_gather_ms", "root_bytes_sparse", "sparse_failed"):
+                for k in ("root_bytes", "with_sparse_gather", "sparse_gather_ms", "root_bytes_sparse", "sparse_failed", "zero_weight_fraction", "auto_layout"):
                     if k in strong:
                         line[k] = strong[k]
                 line["config"]["parallelism"] = "ONE frame per step in %d ray-index slabs (dp%d), RCCL gather of the 28 B/ray payload to rank 0 included" % (world, world)
