@@ -254,7 +254,7 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #define ZOIC_STORE_NT 0   // experiments: 1 = the IMAGE kernels' records leave as non-temporal stores (they never come back; the bokeh table they evict does), 2 = every kernel's
 #endif
 #ifndef ZOIC_PHASE_A_TEST0
-#define ZOIC_PHASE_A_TEST0 0   // 1: phase A of the FAST kernels always takes its own interface-0 test (rounds 3-5; A/B: profiles/ab_r06/ab_no_a0.log)
+#define ZOIC_PHASE_A_TEST0 0   // 1: phase A always takes its own interface-0 test (rounds 3-5; A/B: profiles/ab_r06/ab_no_a0.log)
 #endif
 #ifndef ZOIC_SEARCH_DRAWS
 #define ZOIC_SEARCH_DRAWS 2   // lens draws the retry search of the IMAGE kernels samples per round (one wait for all their records); measured on C3: 1 -> 38.8, 2 -> 41.1, 3 -> 40.4, 4 -> 39.6 Grays/s
@@ -445,14 +445,15 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 const float rx = lens.x * cs - lens.y * sn, ry = lens.x * sn + lens.y * cs;
                 d = V3{rx - o.x, ry - o.y, T.dirZ};
             }
-            // The first try's interface-0 test.  The FAST kernels take it HERE only in waves that hold a dead pixel (whose 27 tries are decided by this
-            // one test: a wave of them never enters the trace); everywhere else every fresh lane is a candidate and the predicated trace's own interface
-            // 0 -- the same FastHit, the same guard band -- takes the decision: a first try that is clipped there leaves the trace dead like one clipped
-            // later and goes to the pool (or, retry-dead, to the dead list) from behind it.  Same rays; [MI355X, profiles/ab_r06/ab_no_a0.log] the test
-            // was 30 instructions a ray that the trace repeats: C4 +3.2 %, C2 +3.1 %, C3 +1.3 % decision-safe; without the dead-pixel exception C5 -3.5 %.
+            // The first try's interface-0 test.  It is taken HERE only in waves that hold a dead pixel (whose 27 tries are decided by this one test: a wave
+            // of them never enters the trace); everywhere else every fresh lane is a candidate and the predicated trace's own interface 0 -- FAST: the same
+            // FastHit and guard band; STRICT: the same sequence of roundings -- takes the decision: a first try that is clipped there leaves the trace dead
+            // like one clipped later and goes to the pool (or, retry-dead, to the dead list) from behind it.  Same rays; [MI355X, profiles/ab_r06/ab_no_a0.log]
+            // the test was 30 (STRICT: 65) instructions a ray that the trace repeats: C4 +2.1 %, C3 +1.4 %, C2 +1.0 % decision-safe, STRICT +2.1 %; without the
+            // dead-pixel exception C5 -3.5 %.
             bool near0 = false;
             bool pass0 = true;
-            if (STRICT || ZOIC_PHASE_A_TEST0 != 0 || anyDead) pass0 = clears_rear(o, d, near0);
+            if (ZOIC_PHASE_A_TEST0 != 0 || anyDead) pass0 = clears_rear(o, d, near0);
             if (searching) {
                 if (GUARD && near0) { unsure = true; searching = false; }   // too close to call: no decision is taken here
                 else if (pass0) { cand = true; searching = false; }
