@@ -288,10 +288,11 @@ zoic_status zoic_camera_create_rays_tile(zoic_camera *cam, uint32_t n, const zoi
                                          uint64_t ray_index_base, uint16_t tid);
 /* The same resident kernel for a GPU consumer's mid-size batch: n <= ZOIC_RESIDENT_MAX_SAMPLES (sx, sy, lensx, lensy) samples in DEVICE memory
  * -> n zoic_ray records in DEVICE memory, what zoic_create_rays_device(cam, n, d_samples, NULL, ray_index_base, d_rays, stream) writes, bit
- * for bit, without a kernel launch: a launch-based call costs 52-76 us whatever it carries, this one ~20-30 us per
- * 65536 samples.  NOT stream-ordered: d_samples must be complete when the call is made (synchronise the stream that produced them), the
+ * for bit, without a kernel launch: a launch-based call costs 52-76 us whatever it carries; this one 30 us for 4096
+ * samples (launch + synchronise: 90) and 68 us for 65 536 (115).  NOT stream-ordered: d_samples must be complete when the call is made (synchronise the stream that produced them), the
  * call returns when d_rays is complete and visible to any kernel launched afterwards.  Pieces of 65536 samples are served one after the
- * other on the mailbox slot of `tid`: beyond a few hundred thousand samples zoic_create_rays_device's one launch is the faster call. */
+ * other on the mailbox slot of `tid` (several threads, several slots: 1.9 Grays/s from four): beyond a few hundred thousand samples per call
+ * zoic_create_rays_device's one launch is the faster call. */
 #define ZOIC_RESIDENT_MAX_SAMPLES 1048576u
 zoic_status zoic_create_rays_device_resident(zoic_camera *cam, uint32_t n, const float *d_samples, zoic_ray *d_rays, uint64_t ray_index_base,
                                              uint16_t tid);

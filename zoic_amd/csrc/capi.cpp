@@ -189,8 +189,14 @@ struct Mailbox {
             std::memset(mem.host, 0, mem.cap);
             if (!dState) e = hipMalloc(reinterpret_cast<void **>(&dState), sizeof(MailDeviceState));
         }
-        if (e == hipSuccess) e = hipMemset(dState, 0, sizeof(MailDeviceState));
         if (e == hipSuccess && !stream) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        // The state is zeroed ON THE RESIDENT KERNEL'S OWN STREAM and waited for.  (hipMemset on device memory returns before the fill has run, and it ran
+        // on the null stream, which a hipStreamNonBlocking stream does not wait for: round 5's order -- memset, then the stream, then the launch -- let the
+        // fill land AFTER the first tile's descriptor, ticket counters and wake lines had been posted; the workers then drew tickets of generation 0, the
+        // tile's batches were never handed out and the render thread waited its 20 s.  One full `-m gpu` run in five: found with the time-out's dump,
+        // "tile 1 with 256 batches of which 1 flagged".)
+        if (e == hipSuccess) e = hipMemsetAsync(dState, 0, sizeof(MailDeviceState), stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) {
             if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
             if (dState) { (void)hipFree(dState); dState = nullptr; }
@@ -850,6 +856,7 @@ zoic_status zoic_camera_create(int device, zoic_camera **out)
         cam->slots[i].cursor = cam->dWorkCursor + i * 2 * kCursorStride;
         e = hipEventCreateWithFlags(&cam->slots[i].done, hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // the two fills above have RUN (hipMemset on device memory is asynchronous; launches may come on non-blocking streams)
     if (e != hipSuccess) {
         zoic_camera_destroy(cam.release());
         return fail(ZOIC_ERR_HIP, std::string("camera allocation: ") + hipGetErrorString(e));
@@ -1298,7 +1305,13 @@ static zoic_status mailbox_await(zoic_camera *cam, unsigned slot, bool wantWorke
             if (zoic_status s = mailbox_ensure_running(cam, slot, wantWorkers)) return s;
             const auto now = std::chrono::steady_clock::now();
             if (!timing) { t0 = now; timing = true; }
-            else if (now - t0 > std::chrono::seconds(20)) return fail(ZOIC_ERR_HIP, "resident kernel did not answer");
+            else if (now - t0 > std::chrono::seconds(20)) {
+                // what the host sees of the slot, for whoever has to find out why (a lost batch shows as one flag short)
+                char why[320];
+                std::snprintf(why, sizeof why, "resident kernel did not answer (slot %u: request %u, tile %u with %u batches of which %u flagged, alive %u, slots in use %u, worker groups %u)",
+                              slot, M.seq[slot], M.tileSeq[slot], M.tileBatches[slot], M.tileSeen[slot], M.header()->alive, M.slotsInUse.load(), M.workerGroups.load());
+                return fail(ZOIC_ERR_HIP, why);
+            }
         }
     }
 }
@@ -1705,6 +1718,7 @@ zoic_status zoic_camera_reset_counters(zoic_camera *cam)
     ZOIC_HIP(cam->mail.stop());
     ZOIC_HIP(hipDeviceSynchronize());
     ZOIC_HIP(hipMemset(cam->dCounters, 0, kCounterSets * sizeof(DeviceCounters)));
+    ZOIC_HIP(hipDeviceSynchronize());   // (a device-memory hipMemset returns before the fill has run, on the null stream: a launch on a non-blocking stream would not wait for it)
     cam->tirInCounters = 0;
     return ZOIC_OK;
 }

@@ -105,6 +105,10 @@ __device__ __forceinline__ void store_uncached(uint4 *p, uint4 q)
 // side as well) once the rounds are over.  Every try is evaluated by the same device functions as everywhere else in the library: same bits as
 // the batch kernels and as the reference's loop order (tests/test_tile_gpu.py, tests/test_boundary_gpu.py).
 constexpr uint32_t kTileStageWords = 576;   // LDS stage per wave (THINLENS: 64 x 7 input dwords, then 64 x 8 record dwords)
+// RAYTRACED waves carry a second area behind it for WIDE batches (64 rays, mailbox.hpp kTileWideSamples): [576, 1088) the batch's 64 records (its 64 x 7 input
+// dwords on arrival), [1088, 1344) the 64 samples, [1344, 1408) the order in which the rays the first pass did not settle go through the 16-ray rounds
+constexpr uint32_t kWideRecs = kTileStageWords, kWideSamp = kWideRecs + 512u, kWideOrder = kWideSamp + 256u, kTileStageWordsKolb = kWideOrder + 64u;
+__host__ __device__ constexpr uint32_t stage_words(int model) { return model == 0 ? kTileStageWords : kTileStageWordsKolb; }
 constexpr uint32_t kKolbBatch = kTileRaysRaytraced;   // rays per wave pass (mailbox.hpp)
 // LDS stage of a wave (kTileStageWords dwords): [0, 128) the finished records, 8 dwords per ray (what the output stage reads);
 // [128, 512) the rays' state, 24 dwords each; [384, 496) the batch's input rows on arrival (dead before the state is written);
@@ -388,6 +392,62 @@ __device__ __forceinline__ void kolb_wave_rays(const KolbTable &T, const BokehTa
     wave_lds_fence();
 }
 
+// ---- WIDE batches: 64 rays of a large tile (mailbox.hpp kTileWideSamples) -----------------------------------------------------------------
+// Pass 1, one ray per lane: the reference's first try (set-up, the sample's own lens point, x-only translation, the trace) for every ray that is
+// nothing special -- inside the LUT, not a dead pixel, not at the LUT's end (GUARD), a plain sample in [0,1)^2 off the disk mapping's centre.  A
+// ray whose first try gets through (GUARD: outside every guard band) is FINISHED: origin, direction, weight, flag word 0 -- the bits
+// kolb_wave_rays' round 0 gives it (same set-up, sampler and trace arithmetic; a first success wins whatever the speculative tries 1-3 did) and
+// the batch kernels' phase A.  Everything else -- failed or undecided first tries, dead pixels, hostile samples -- goes through kolb_wave_rays
+// 16 rays at a time, FROM SCRATCH (try 0 again: the same failure, the same TIR bump, counted there), so that no rule exists twice: the caller's
+// group loop (ONE call site of kolb_wave_rays for both batch shapes: inlined twice, the FAST kernels needed 262 VGPRs -- more than two waves per SIMD
+// have -- where they need 226 with one).
+template <bool STRICT, bool GUARD, int NS>
+__device__ __forceinline__ uint32_t kolb_wide_first_pass(const KolbTable &T, const BokehTables &B, const float2 *lutLds, const float *bokehLds, float *stage,
+                                                         float4 sample, uint32_t cnt, uint32_t lane, uint32_t &succ)
+{
+    float4 *recs = reinterpret_cast<float4 *>(stage + kWideRecs);
+    float4 *samp = reinterpret_cast<float4 *>(stage + kWideSamp);
+    uint32_t *order = reinterpret_cast<uint32_t *>(stage + kWideOrder);
+    const bool have = lane < cnt;
+    const RaySetup rs = setup_ray<STRICT>(T, lutLds, sample.x, sample.y);
+    const float u = sample.z, v = sample.w;
+    const bool plain = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
+    const bool cand = have && plain && !rs.dead && (rs.flags & 1u) == 0u && !(GUARD && T.useLUT && rs.lutEdge);
+    V2 lens = lens_sample<STRICT>(T, B, bokehLds, u, v);                     // zoic.cpp:1870
+    V3 o{rs.o0x, rs.o0y, T.originShift}, d;
+    if (!T.useLUT) d = V3{(lens.x * T.rearAperture) - o.x, (lens.y * T.rearAperture) - o.y, T.dirZ};   // zoic.cpp:1873-1877
+    else {                                                                   // zoic.cpp:1913-1924: the first sample is translated in x only
+        lens.x *= rs.maxScale; lens.y *= rs.maxScale;
+        lens.x += rs.translation;
+        const float rx = lens.x * rs.cs - lens.y * rs.sn, ry = lens.x * rs.sn + lens.y * rs.cs;
+        d = V3{rx - o.x, ry - o.y, T.dirZ};
+    }
+    bool ok = false, unsure = false;
+    if constexpr (!STRICT && NS > 0) {
+        unsigned long long tirMask, unsureMask;
+        const unsigned long long alive = trace_lens_fast_pred<NS, GUARD>(kernarg_fast_surfaces(), o, d, __ballot(cand), tirMask, unsureMask);
+        ok = mask_bit(alive, lane);
+        if constexpr (GUARD) unsure = mask_bit(unsureMask, lane);
+    } else if (cand) {
+        uint32_t tirTry = 0;   // (a first try that is totally reflected is not finished here: its bump is counted where the ray ends)
+        if constexpr (STRICT) ok = trace_lens_strict(T, o, d, tirTry);
+        else ok = trace_lens_fast_rolled(T, o, d, tirTry, GUARD ? &unsure : nullptr);
+    }
+    const bool done = cand && ok && !unsure;
+    if (done) {
+        float w = 1.0f;
+        if (T.exposureOn) w *= T.exposureMul;                               // zoic.cpp:1981-1987
+        recs[2u * lane] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);   // zoic.cpp:1960-1961
+        recs[2u * lane + 1u] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, 0u));
+        succ += 1u;
+    }
+    samp[lane] = sample;
+    const unsigned long long pending = __ballot(have && !done);
+    if (have && !done) order[mask_rank(pending)] = lane;
+    wave_lds_fence();
+    return static_cast<uint32_t>(__popcll(pending));   // the rays left for kolb_wave_rays: order[0 .. n), their samples in samp[]
+}
+
 // system scope (mapped host memory: never from / into a GPU cache) and agent scope (the job table: coherent across the XCDs' L2s)
 // (the addresses arrive as integers: say "global" so that these are global_load / global_store, not flat_*)
 typedef uint32_t __attribute__((address_space(1))) GlobalWord;
@@ -440,7 +500,7 @@ template <int MODEL, int MODE, int NS>
 __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, const ThinTable Th, const BokehTables B, char *mapped,
                                                              MailDeviceState *st, DeviceCounters *counters, uint32_t ldsWords, uint32_t totalWaves)
 {
-    constexpr uint32_t kRays = MODEL == 0 ? 64u : kKolbBatch;   // the LARGEST batch of a tile (tile_rays_per_batch, mailbox.hpp: small RAYTRACED tiles are cut into half batches)
+    constexpr uint32_t kRays = 64u;   // the LARGEST batch of a tile (tile_rays_per_batch, mailbox.hpp: THINLENS always, RAYTRACED from kTileWideSamples samples on; 16 otherwise)
     if (threadIdx.x < kLutEntries) {
         zoicDynLds[2 * threadIdx.x] = T.lutMaxScale[threadIdx.x];
         zoicDynLds[2 * threadIdx.x + 1] = T.lutCentroidX[threadIdx.x];
@@ -456,7 +516,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
     const uint32_t waveId = blockIdx.x * (kMailBlock / 64u) + (threadIdx.x >> 6);
     const bool slotRole = waveId < kMailSlots;
     const uint32_t slot = slotRole ? waveId : 0u;
-    float *stage = zoicDynLds + kLutLdsWords + ldsWords + (threadIdx.x >> 6) * kTileStageWords;
+    float *stage = zoicDynLds + kLutLdsWords + ldsWords + (threadIdx.x >> 6) * stage_words(MODEL);
     MailHeader *header = reinterpret_cast<MailHeader *>(mapped);
     const MailRequest *requests = reinterpret_cast<const MailRequest *>(mapped + kMailRequestsOffset);
     MailReply *replies = reinterpret_cast<MailReply *>(mapped + kMailRepliesOffset);
@@ -685,7 +745,9 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
 
         // ---- the pass's samples: the slot's one sample in lane 0, or 64 consecutive rows of the tile --------------------------
         // (lane r holds ray r's sample; RAYTRACED shares the wave's lanes among the rays' tries afterwards, kolb_wave_rays)
-        constexpr uint32_t kIn = MODEL == 0 ? 0u : kStageInput;   // where the input rows land in the wave's stage
+        // where the input rows land in the wave's stage: THINLENS at its start, a 16-ray RAYTRACED batch in the state area, a WIDE one (64 rays) in its record area
+        const bool wide = MODEL != 0 && work == 2u && jobRays > kKolbBatch;
+        const uint32_t kIn = MODEL == 0 ? 0u : (wide ? kWideRecs : kStageInput);
         bool active = lane == 0u;
         uint32_t first = 0, cnt = 1;
         unsigned long long rayBase = 0;
@@ -703,10 +765,11 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             const uint32_t total = cnt * 7u;
             constexpr uint32_t kLoads = (kRays * 7u + 63u) / 64u;
             uint32_t w7[kLoads];
+            // (wave-uniform guards: a 16-ray batch issues two loads, not seven -- every one of them is a PCIe read)
 #pragma unroll
-            for (uint32_t k = 0; k < kLoads; ++k) { const uint32_t j = k * 64u + lane; w7[k] = load_sys(src + (j < total ? j : total - 1u)); }
+            for (uint32_t k = 0; k < kLoads; ++k) { const uint32_t j = k * 64u + lane; w7[k] = 0u; if (k * 64u < total) w7[k] = load_sys(src + (j < total ? j : total - 1u)); }
 #pragma unroll
-            for (uint32_t k = 0; k < kLoads; ++k) { const uint32_t j = k * 64u + lane; if (j < kRays * 7u) stage[kIn + j] = __builtin_bit_cast(float, w7[k]); }
+            for (uint32_t k = 0; k < kLoads; ++k) { const uint32_t j = k * 64u + lane; if (k * 64u < total && j < total) stage[kIn + j] = __builtin_bit_cast(float, w7[k]); }
             wave_lds_fence();
             active = lane < cnt;
             const uint32_t row = kIn + (active ? lane : 0u) * 7u;
@@ -745,8 +808,24 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
             const bool tileWork = work == 2u;
             const uint32_t seed = T.seed;
             const auto rngOf = [&](uint32_t ray) { return tileWork ? rng_for_ray(seed, rayBase + ray) : rng; };
-            kolb_wave_rays<MODE == 0, MODE == 1, NS>(T, B, lutLds, bokehLds, stage, s, cnt, lane, rngOf, succ, vign, tir);
+            // a 16-ray batch is ONE group: its own rays in order; a wide batch: the first pass, then the rays it left, 16 at a time, their records
+            // copied to the batch's 64-record area
+            uint32_t nLeft = cnt;
+            const uint32_t *order = reinterpret_cast<const uint32_t *>(stage + kWideOrder);
+            if (wide) nLeft = kolb_wide_first_pass<MODE == 0, MODE == 1, NS>(T, B, lutLds, bokehLds, stage, s, cnt, lane, succ);
+            for (uint32_t g0 = 0; g0 < nLeft; g0 += kKolbBatch) {
+                const uint32_t cntG = nLeft - g0 < kKolbBatch ? nLeft - g0 : kKolbBatch;
+                float4 sG = s;
+                if (wide) sG = reinterpret_cast<const float4 *>(stage + kWideSamp)[order[g0 + (lane < cntG ? lane : 0u)]];
+                kolb_wave_rays<MODE == 0, MODE == 1, NS>(T, B, lutLds, bokehLds, stage, sG, cntG, lane, [&](uint32_t r) { return rngOf(wide ? order[g0 + r] : r); }, succ, vign, tir);
+                if (wide) {   // (kolb_wave_rays ends behind an LDS fence: the group's records stand in stage[0 .. 8 cntG))
+                    float *rec64 = stage + kWideRecs;
+                    for (uint32_t j = lane; j < cntG * 8u; j += 64u) rec64[order[g0 + (j >> 3)] * 8u + (j & 7u)] = stage[j];
+                    wave_lds_fence();
+                }
+            }
         }
+        const float *recStage = stage + ((MODEL != 0 && wide) ? kWideRecs : 0u);   // where the batch's records stand
 
 #ifdef ZOIC_TILE_TIMING
         const unsigned long long tt2 = wall_clock64();
@@ -771,7 +850,7 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
 #pragma unroll
             for (uint32_t k = 0; k < (kRays * 8u + 63u) / 64u; ++k) {
                 const uint32_t j = k * 64u + lane;
-                if (j < total) store_sys(dst + j, __builtin_bit_cast(uint32_t, stage[j]));
+                if (k * 64u < total && j < total) store_sys(dst + j, __builtin_bit_cast(uint32_t, recStage[j]));
             }
             wave_lds_fence();
         } else {
@@ -780,9 +859,9 @@ __global__ __launch_bounds__(kMailBlock) void mailbox_kernel(const KolbTable T, 
 #pragma unroll
             for (uint32_t k = 0; k < (kRays * 21u + 63u) / 64u; ++k) {
                 const uint32_t j = k * 64u + lane;
-                if (j < total) {
+                if (k * 64u < total && j < total) {
                     const uint32_t ray = j / 21u, f = j - ray * 21u;
-                    const float *r = stage + ray * 8u;
+                    const float *r = recStage + ray * 8u;
                     const bool retried = (__builtin_bit_cast(uint32_t, r[7]) & 1u) != 0u;
                     float v = 0.0f;                                  // dOdx (6-8), dDdx (12-14); dOdy / dDdy of first-try rays
                     if (f < 6u) v = r[f];                            // origin, dir
@@ -851,7 +930,7 @@ int launch_mailbox(const KolbTable &kolb, const ThinTable &thin, const BokehTabl
     const bool image = (model == 0 ? thin.useImage : kolb.useImage) != 0;
     const uint32_t ldsWords = (image && bokeh.ldsWords > 0 && bokeh.ldsWords <= 10240) ? static_cast<uint32_t>(bokeh.ldsWords) : 0u;
     const uint32_t groups = kMailSlotGroups + workerGroups;
-    const size_t lds = (kLutLdsWords + ldsWords + (kMailBlock / 64u) * kTileStageWords) * sizeof(float);
+    const size_t lds = (kLutLdsWords + ldsWords + (kMailBlock / 64u) * stage_words(model)) * sizeof(float);
 #define ZOIC_LAUNCH_MAILBOX(MODEL_, MODE_, NS_)                                                                                  \
     hipLaunchKernelGGL((mailbox_kernel<MODEL_, MODE_, NS_>), dim3(groups), dim3(kMailBlock), lds, static_cast<hipStream_t>(stream), kolb, thin, bokeh, \
                        static_cast<char *>(d_mapped), d_state, d_counters, ldsWords, groups * (kMailBlock / 64u))

@@ -52,6 +52,14 @@ static_assert(sizeof(MailRequest) == 64 && sizeof(MailTileRequest) == 64 && size
 #define ZOIC_TILE_RAYS 16   // rays a resident wave holds at once (RAYTRACED): 64 / this lanes per ray in the first round
 #endif
 constexpr uint32_t kTileRaysRaytraced = ZOIC_TILE_RAYS, kTileRaysThin = 64;
+// LARGE RAYTRACED tiles (round 6): from kTileWideSamples samples on a batch is 64 rays -- a first try at ONE RAY PER LANE (what 84 % of a double Gauss's rays
+// need), then the rays it did not settle in groups of kTileRaysRaytraced through the tries-side-by-side rounds (mailbox.hip kolb_wave_wide).  Four lanes per
+// ray are a bucket's LATENCY (a 4096-sample tile waits for its slowest 16-ray batch); a 65 536-sample request is THROUGHPUT: at 16 rays per wave pass the tile
+// workers top out at ~0.6 Grays/s for one request whatever its rows cross (a device-resident one: 109 us, VERDICT r5 #7 asked for 25).
+#ifndef ZOIC_TILE_WIDE_SAMPLES
+#define ZOIC_TILE_WIDE_SAMPLES 16384
+#endif
+constexpr uint32_t kTileRaysWide = 64, kTileWideSamples = ZOIC_TILE_WIDE_SAMPLES;
 // Samples per batch of an n-sample tile (host and kernel agree on this; the descriptor carries it).  A RAYTRACED wave shares its 64 lanes
 // among the rays it holds, so half a batch of rays finishes in fewer rounds -- and serves half the rays per wave pass.  Measured
 // [MI355X, profiles/ab_r05/tile_latency_v6.txt]: 8 instead of 16 rays for tiles up to 8192 samples: double Gauss 4096 samples 36.7 ->
@@ -62,7 +70,7 @@ inline
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-uint32_t tile_rays_per_batch(bool thinLens, uint32_t n) { (void)n; return thinLens ? kTileRaysThin : kTileRaysRaytraced; }
+uint32_t tile_rays_per_batch(bool thinLens, uint32_t n) { return thinLens ? kTileRaysThin : (n >= kTileWideSamples ? kTileRaysWide : kTileRaysRaytraced); }
 #endif   // samples per batch of a tile (mailbox.hip: RAYTRACED spends four lanes on a ray)
 constexpr uint32_t kTileMaxBatches = kTileMaxSamples / kTileRaysRaytraced;   // (>= 8192 / (kTileRaysRaytraced / 2))
 constexpr size_t kMailRequestsOffset = 64, kMailRepliesOffset = kMailRequestsOffset + 64 * kMailSlots,
