@@ -381,7 +381,9 @@ def test_tile_fuzz_random_cameras_hostile_samples_both_modes(gpu):
             cam.close()
             return
         cam.set_precision(PRECISION_FAST if fast else PRECISION_STRICT)
-        n = int(rs.randint(1, 3000))
+        # a bucket, or (one camera in four) a tile large enough for the resident kernel's WIDE batches (64 rays per wave pass from 16 384 samples on,
+        # mailbox.hpp): pageable rows go through 16 384-row pieces, so such a call is wide pieces + a ragged 16-ray-batch remainder
+        n = int(rs.randint(1, 3000)) if rs.rand() < 0.75 else int(rs.randint(16384, 40000))
         a, _s, base = inputs_of("C2", n, where)
         hostile = rs.rand(n, 7) < 0.01
         a[hostile] = special[rs.randint(len(special), size=int(hostile.sum()))]
