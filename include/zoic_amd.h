@@ -16,8 +16,8 @@
  * thread with no sample in flight, and camera_create_ray concurrently from every render thread, zoic.cpp:1752):
  *   - zoic_camera_create / _update / _destroy / _set_* / _reset_counters: one thread at a time per camera, and no
  *     ray call of that camera running on another thread.  (_update and _destroy wait for launches still queued.)
- *   - zoic_create_rays_device / _host / _arnold, zoic_camera_create_ray, zoic_camera_reverse_ray,
- *     zoic_camera_get_counters: any number of host threads on one camera at once.  Each call works on private
+ *   - zoic_create_rays_device / _host / _arnold / _device_resident, zoic_camera_create_ray, zoic_camera_create_rays_tile, zoic_tile_submit / _wait /
+ *     _done (one tile per thread), zoic_camera_reverse_ray, zoic_camera_get_counters, zoic_camera_set_wait_mode: any number of host threads on one camera at once.  Each call works on private
  *     scratch and private HIP streams and waits only for its own work; results do not depend on the interleaving
  *     (batched calls key every ray's retry stream by its global ray index, the per-sample call by its tid).
  *   - No entry point changes the calling thread's current HIP device.
