@@ -253,6 +253,9 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #ifndef ZOIC_STORE_NT
 #define ZOIC_STORE_NT 0   // experiments: 1 = the IMAGE kernels' records leave as non-temporal stores (they never come back; the bokeh table they evict does), 2 = every kernel's
 #endif
+#ifndef ZOIC_DEAD_WAVE_SAMPLER
+#define ZOIC_DEAD_WAVE_SAMPLER 0   // 1: phase A samples the lens even in waves of nothing but dead pixels (rounds 3-5; A/B: profiles/ab_r06/ab_dead_wave.log)
+#endif
 #ifndef ZOIC_PHASE_A_TEST0
 #define ZOIC_PHASE_A_TEST0 0   // 1: phase A always takes its own interface-0 test (rounds 3-5; A/B: profiles/ab_r06/ab_no_a0.log)
 #endif
@@ -425,15 +428,22 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             // dead pixel (outside the image circle, LUT entries zero): whatever finite point the sampler returns, the direction
             // is (0 - o.x, 0 - o.y, dirZ); samples in [0,1)^2 off the disk mapping's 0/0 centre need no sampler
             V2 lens;
+            const bool anyDead = __ballot(dead) != 0ull;
+            // plain: a sample in [0,1)^2 off the disk mapping's 0/0 centre -- for a dead pixel the sampler's (finite) point is never looked at
+            bool plainSample = true;
+            if (anyDead) plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));   // wave-uniform: most waves hold no dead pixel and skip these compares
 #if ZOIC_EXP_WHATIF == 2
             if constexpr (PROBE) lens = concentric_disk_f32(u, v);
 #else
             if constexpr (PROBE) lens = bokeh_cells_finish<STRICT>(B, T.bokehW, T.bokehH, v, probe);
 #endif
-            else lens = sample_lens(u, v);
-            const bool anyDead = __ballot(dead) != 0ull;
-            if (anyDead) {   // wave-uniform: most waves hold no dead pixel and skip these dozen compares
-                const bool plainSample = (u >= 0.0f) & (u < 1.0f) & (v >= 0.0f) & (v < 1.0f) & !((u == 0.5f) & (v == 0.5f));
+            else {
+                // a wave of nothing but dead pixels with plain samples (the corners of a frame wider than the image circle: three quarters of C5's) needs no
+                // lens sample at all: ~35 instructions a ray of the ~250 such a ray costs [MI355X, profiles/ab_r06/ab_dead_wave.log]
+                lens = V2{0.0f, 0.0f};
+                if (ZOIC_DEAD_WAVE_SAMPLER != 0 || __ballot(active && !(dead && plainSample)) != 0ull) lens = sample_lens(u, v);
+            }
+            if (anyDead) {
                 if (dead && plainSample) lens = V2{0.0f, 0.0f};
                 finiteSample = (fabsf(lens.x) <= 3.0e38f) && (fabsf(lens.y) <= 3.0e38f);
             }
