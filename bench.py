@@ -89,7 +89,8 @@ def parse_args():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config array")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-frame (north-star configs 4/5) measurement")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity")
+    ap.add_argument("--no-device-state", action="store_true", help="skip the second of frames with the clock / power sensors read beside it")
+    ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity --no-device-state")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of one repetition of a CPU baseline leg")
     ap.add_argument("--no-sparse-leg", action="store_true", help="N > 1: skip the sparse gather's timing (it runs last, behind everything else)")
     ap.add_argument("--no-single-process", action="store_true", help="N > 1: skip the zoic_frame_* measurement (rank 0 driving all devices)")
@@ -349,11 +350,72 @@ def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_ra
     return elapsed, kernel_ms
 
 
+def device_sensor_files(torch, device_index):
+    """hwmon files (shader clock, socket power) of the card whose PCI address is the HIP device's -- a box shows every card of
+    its host, so `card0` is usually another GPU.  {} when sysfs has none (the leg is then skipped)."""
+    import glob
+    pr = torch.cuda.get_device_properties(device_index)
+    addr = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    out = {}
+    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if addr not in os.path.realpath(card):
+            continue
+        for name, pat in (("sclk_mhz", "hwmon/hwmon*/freq1_input"), ("power_w", "hwmon/hwmon*/power1_input"), ("power_w", "hwmon/hwmon*/power1_average")):
+            for f in glob.glob(os.path.join(card, pat)):
+                out.setdefault(name, f)
+    return out
+
+
+def device_state_entry(torch, cam, cfg, n, base, dev, seconds=1.0):
+    """Shader clock and socket power WHILE the headline kernel runs (round 6: every batch kernel runs against the socket's power
+    limit, 1.31-1.34 kW, at 2.06-2.34 GHz instead of the 2.4 GHz the architectural peaks are quoted at -- DESIGN section 5).
+    About `seconds` of back-to-back frames OUTSIDE the timed region, the sensors read every 20 ms from a second thread."""
+    import threading
+    files = device_sensor_files(torch, dev.index or 0)
+    if not files:
+        return None
+    samples = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=base)
+    out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device=dev))
+    rows, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            row = {}
+            for k, f in files.items():
+                try:
+                    row[k] = float(open(f).read().split()[0]) * 1e-6
+                except (OSError, ValueError, IndexError):
+                    pass
+            rows.append((time.perf_counter(), row))
+            time.sleep(0.02)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    launches = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            cam.create_rays(samples, ray_index_base=base, out=out)
+        launches += 10
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    stop.set()
+    th.join()
+    del samples, out
+    loaded = [r for t, r in rows if t0 + 0.4 * (t1 - t0) <= t <= t1]      # the clock settles within ~0.3 s of load
+    ent = {"launches": launches, "mrays_s": round(n * launches / (t1 - t0) / 1e6, 1), "samples": len(loaded)}
+    for k in ("sclk_mhz", "power_w"):
+        v = [r[k] for r in loaded if k in r]
+        if v:
+            ent[k] = round(sum(v) / len(v))
+    return ent
+
+
 def frame_stats(counters, n_done):
     return round(counters["vignettedRays"] / max(n_done, 1), 5)
 
 
-def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, parity):
+def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, parity, device_state=False):
     from zoic_amd.workloads import CONFIGS, ray_count
     cfg = CONFIGS[cfg_name]
     n = ray_count(cfg_name)
@@ -368,6 +430,9 @@ def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, par
     for k in ("traffic", "lane_instr", "lane_util", "valu_frac"):
         if roof.get(k) is not None:
             ent[k] = roof[k]
+    state = device_state_entry(torch, cam, cfg, n, 0, dev, seconds=0.6) if device_state else None
+    if state:
+        ent.update({k: state[k] for k in ("sclk_mhz", "power_w") if k in state})
     if parity:
         ent.update(parity_probe(cam, cfg_name, precision))
     cam.close()
@@ -707,7 +772,7 @@ def flush_c_stdio():
 def main():
     args = parse_args()
     if args.only_headline:
-        args.no_configs = args.no_sharded = args.no_host_path = args.no_cpu_baseline = args.no_parity = True
+        args.no_configs = args.no_sharded = args.no_host_path = args.no_cpu_baseline = args.no_parity = args.no_device_state = True
     import torch
     from zoic_amd.workloads import CONFIGS, ray_count
 
@@ -765,6 +830,14 @@ def main():
             "zero_weight": frame_stats(counters, counters["succesRays"] + counters["vignettedRays"]),
             "target_mrays_s": round(NORTH_STAR_MRAYS_1GPU * (1.0 if world == 1 else 0.75 * world)),
         }
+        if world == 1 and not args.no_device_state:
+            # outside the timed region: what clock did the kernel get?  (the peaks above are at 2.4 GHz; the socket's power limit decides)
+            state = device_state_entry(torch, cam, cfg, n, base, dev)
+            if state:
+                line["device_state"] = state
+                if state.get("sclk_mhz"):
+                    line["roofline"]["sclk_mhz_under_load"] = state["sclk_mhz"]
+                    line["roofline"]["frac_at_measured_clock"] = round(line["roofline"]["frac"] * 2400.0 / state["sclk_mhz"], 4) if line["roofline"]["bound"] == "valu" else None
         if not args.no_parity:
             line["parity"] = parity_probe(cam, args.config, args.precision)
         if not args.no_host_path and world == 1:
@@ -780,7 +853,7 @@ def main():
         for cname, prec, st, wu in (("C1", "fast", 20, 3), ("C2", "fast", 20, 3), ("C4", "fast", 10, 2), ("C5", "fast", 4, 1), ("C3", "strict", 8, 2)):
             if cname == args.config and prec == args.precision:
                 continue
-            ents.append(config_entry(torch, cname, prec, dev, local_rank, st, wu, not args.no_parity))
+            ents.append(config_entry(torch, cname, prec, dev, local_rank, st, wu, not args.no_parity, not args.no_device_state))
         line["configs"] = ents
 
     if world > 1:
