@@ -79,7 +79,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE if a launcher set it, else 1)")
     ap.add_argument("--dry-launch", action="store_true", help="CPU self-test of the launcher: ranks meet over gloo, rank 0 prints the world it saw")
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed launches before the timed ones (the first ~25 ms of launches after an idle gap run 5-15 %% slow: DESIGN section 5)")
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--precision", default="fast", choices=["fast", "unchecked", "strict"],
                     help="fast = ZOIC_PRECISION_FAST (decision-safe), unchecked = ZOIC_PRECISION_FAST_UNCHECKED, strict = bit-exact")
@@ -850,7 +850,9 @@ def main():
 
     if not args.no_configs and world == 1:
         ents = []
-        for cname, prec, st, wu in (("C1", "fast", 20, 3), ("C2", "fast", 20, 3), ("C4", "fast", 10, 2), ("C5", "fast", 4, 1), ("C3", "strict", 8, 2)):
+        # sub-millisecond frames get enough warm-up launches to leave the ~25 ms after an idle gap in which launches run slow (C2: 32.1 Grays/s over
+        # launches 4-23, 35.9 from launch 50 on: profiles/ab_r06/warmup_steps.txt)
+        for cname, prec, st, wu in (("C1", "fast", 400, 300), ("C2", "fast", 200, 60), ("C4", "fast", 10, 5), ("C5", "fast", 4, 1), ("C3", "strict", 8, 4)):
             if cname == args.config and prec == args.precision:
                 continue
             ents.append(config_entry(torch, cname, prec, dev, local_rank, st, wu, not args.no_parity, not args.no_device_state))

@@ -23,7 +23,8 @@ def sysfs_files():
     print("HIP device 0 at PCI %s -> %s" % (addr, [os.path.realpath(c) for c in cards]), flush=True)
     for card in cards:
         for name, pat in (("sclk_mhz", "hwmon/hwmon*/freq1_input"), ("mclk_mhz", "hwmon/hwmon*/freq2_input"), ("power_w", "hwmon/hwmon*/power1_average"),
-                          ("power_in_w", "hwmon/hwmon*/power1_input"), ("temp_c", "hwmon/hwmon*/temp1_input"), ("temp_hbm_c", "hwmon/hwmon*/temp3_input"), ("busy", "gpu_busy_percent")):
+                          ("power_in_w", "hwmon/hwmon*/power1_input"), ("temp_c", "hwmon/hwmon*/temp1_input"), ("temp_hbm_c", "hwmon/hwmon*/temp3_input"), ("busy", "gpu_busy_percent"),
+                          ("fclk_mhz", "pp_dpm_fclk"), ("socclk_mhz", "pp_dpm_socclk"), ("dpm_mclk_mhz", "pp_dpm_mclk"), ("dpm_sclk_mhz", "pp_dpm_sclk")):
             for f in glob.glob(os.path.join(card, pat)):
                 out.setdefault(name, f)
     return out
@@ -31,14 +32,20 @@ def sysfs_files():
 
 def read(f):
     try:
-        return float(open(f).read().split()[0])
+        txt = open(f).read()
+        if "pp_dpm" in f:                        # "0: 1250Mhz *" lines: the level in use carries the star
+            for ln in txt.splitlines():
+                if ln.strip().endswith("*"):
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()) * 1e6
+            return None
+        return float(txt.split()[0])
     except Exception:
         return None
 
 
 files = sysfs_files()
 print("sysfs:", files, flush=True)
-scale = {"sclk_mhz": 1e-6, "mclk_mhz": 1e-6, "power_w": 1e-6, "power_in_w": 1e-6, "temp_c": 1e-3, "temp_hbm_c": 1e-3, "busy": 1.0}
+scale = {"fclk_mhz": 1e-6, "socclk_mhz": 1e-6, "dpm_mclk_mhz": 1e-6, "dpm_sclk_mhz": 1e-6, "sclk_mhz": 1e-6, "mclk_mhz": 1e-6, "power_w": 1e-6, "power_in_w": 1e-6, "temp_c": 1e-3, "temp_hbm_c": 1e-3, "busy": 1.0}
 samples, stop = [], False
 
 
