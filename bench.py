@@ -89,6 +89,7 @@ def parse_args():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config array")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-frame (north-star configs 4/5) measurement")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--placement-candidates", type=int, default=3, help="allocations of each frame buffer to choose the pair from (1: the plain first allocations; zoic_amd/placement.py)")
     ap.add_argument("--no-device-state", action="store_true", help="skip the second of frames with the clock / power sensors read beside it")
     ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity --no-device-state")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of one repetition of a CPU baseline leg")
@@ -318,11 +319,19 @@ def max_over_ranks(torch, dist, seconds, dev):
     return float(t.item())
 
 
-def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_rank=0):
+def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_rank=0, keep=None, candidates=3):
     """`steps` launches of one frame of n samples (resident in HBM), bracketed by barrier + synchronize on both sides.
-    Returns (elapsed seconds: max over ranks, mean kernel ms by HIP events on the launch stream)."""
+    Returns (elapsed seconds: max over ranks, mean kernel ms by HIP events on the launch stream).
+
+    The frame's two buffers are allocated the way a renderer would allocate them once per session: `candidates` allocations of
+    each, the pair the camera runs fastest on kept (zoic_amd/placement.py -- which allocations hold the sample stream and the
+    ray stream is worth up to 12 % on the headline; `keep["placement"]` has every pair's rate, the plain first pair's included).
+    `keep` (a dict) also receives the buffers instead of their being freed (the device_state leg runs on the same pair)."""
+    from zoic_amd.placement import pick_frame_buffers
     samples = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=base)
-    out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device=dev))
+    samples, out, placement = pick_frame_buffers(cam, samples, candidates=candidates, ray_index_base=base)
+    if keep is not None:
+        keep["placement"] = placement
     for _ in range(warmup):
         cam.create_rays(samples, ray_index_base=base, out=out)
     torch.cuda.synchronize()
@@ -346,6 +355,8 @@ def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_ra
     if dist:
         elapsed = max_over_ranks(torch, dist, elapsed, dev)
     kernel_ms = ev0.elapsed_time(ev1) / max(steps, 1)
+    if keep is not None and keep.get("hold"):
+        keep["samples"], keep["out"] = samples, out
     del samples, out
     return elapsed, kernel_ms
 
@@ -366,7 +377,7 @@ def device_sensor_files(torch, device_index):
     return out
 
 
-def device_state_entry(torch, cam, cfg, n, base, dev, seconds=1.0):
+def device_state_entry(torch, cam, cfg, n, base, dev, seconds=1.0, buffers=None):
     """Shader clock and socket power WHILE the headline kernel runs (round 6: every batch kernel runs against the socket's power
     limit, 1.31-1.34 kW, at 2.06-2.34 GHz instead of the 2.4 GHz the architectural peaks are quoted at -- DESIGN section 5).
     About `seconds` of back-to-back frames OUTSIDE the timed region, the sensors read every 20 ms from a second thread."""
@@ -374,8 +385,11 @@ def device_state_entry(torch, cam, cfg, n, base, dev, seconds=1.0):
     files = device_sensor_files(torch, dev.index or 0)
     if not files:
         return None
-    samples = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=base)
-    out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device=dev))
+    if buffers:
+        samples, out = buffers
+    else:
+        samples = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=base)
+        out = dict(rays=torch.empty((n, 8), dtype=torch.float32, device=dev))
     rows, stop = [], threading.Event()
 
     def sampler():
@@ -415,12 +429,13 @@ def frame_stats(counters, n_done):
     return round(counters["vignettedRays"] / max(n_done, 1), 5)
 
 
-def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, parity, device_state=False):
+def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, parity, device_state=False, candidates=3):
     from zoic_amd.workloads import CONFIGS, ray_count
     cfg = CONFIGS[cfg_name]
     n = ray_count(cfg_name)
     cam = make_camera(cfg_name, precision, local_rank)
-    elapsed, kernel_ms = time_frame(torch, cam, cfg, n, 0, steps, warmup, dev)
+    keep = {"hold": bool(device_state)}
+    elapsed, kernel_ms = time_frame(torch, cam, cfg, n, 0, steps, warmup, dev, keep=keep, candidates=candidates)
     counters = cam.counters()
     thin = cfg["params"]["lensModel"] == 0
     roof = roofline_block(cfg_name, precision, n, kernel_ms, thin)
@@ -430,7 +445,10 @@ def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, par
     for k in ("traffic", "lane_instr", "lane_util", "valu_frac"):
         if roof.get(k) is not None:
             ent[k] = roof[k]
-    state = device_state_entry(torch, cam, cfg, n, 0, dev, seconds=0.6) if device_state else None
+    pl = keep.get("placement") or {}
+    if pl.get("rates_mrays_s"):
+        ent["placement"] = {k: pl[k] for k in ("candidates", "first_pair_mrays_s", "chosen_pair_mrays_s", "slowest_pair_mrays_s")}
+    state = device_state_entry(torch, cam, cfg, n, 0, dev, seconds=0.6, buffers=(keep.pop("samples"), keep.pop("out"))) if device_state else None
     if state:
         ent.update({k: state[k] for k in ("sclk_mhz", "power_w") if k in state})
     if parity:
@@ -813,7 +831,8 @@ def main():
     frame = args.rays or ray_count(args.config)
     n, base, n_total = frame, rank * frame, frame * world        # weak leg: rank r renders frame r (distinct global ray indices)
     cam = make_camera(args.config, args.precision, local_rank)
-    elapsed, kernel_ms = time_frame(torch, cam, cfg, n, base, args.steps, args.warmup, dev, dist, local_rank)
+    keep = {"hold": world == 1 and not args.no_device_state}
+    elapsed, kernel_ms = time_frame(torch, cam, cfg, n, base, args.steps, args.warmup, dev, dist, local_rank, keep=keep, candidates=args.placement_candidates)
 
     line = None
     if rank == 0:
@@ -830,9 +849,12 @@ def main():
             "zero_weight": frame_stats(counters, counters["succesRays"] + counters["vignettedRays"]),
             "target_mrays_s": round(NORTH_STAR_MRAYS_1GPU * (1.0 if world == 1 else 0.75 * world)),
         }
+        # which allocations hold the frame (zoic_amd/placement.py): every (sample buffer, ray buffer) pair's rate over a few frames
+        # BEFORE the timed region; `first_pair_mrays_s` is what the plain first allocations would have given
+        line["placement"] = keep.get("placement")
         if world == 1 and not args.no_device_state:
             # outside the timed region: what clock did the kernel get?  (the peaks above are at 2.4 GHz; the socket's power limit decides)
-            state = device_state_entry(torch, cam, cfg, n, base, dev)
+            state = device_state_entry(torch, cam, cfg, n, base, dev, buffers=(keep.pop("samples"), keep.pop("out")))
             if state:
                 line["device_state"] = state
                 if state.get("sclk_mhz"):
@@ -855,7 +877,7 @@ def main():
         for cname, prec, st, wu in (("C1", "fast", 400, 300), ("C2", "fast", 200, 60), ("C4", "fast", 10, 5), ("C5", "fast", 4, 1), ("C3", "strict", 8, 4)):
             if cname == args.config and prec == args.precision:
                 continue
-            ents.append(config_entry(torch, cname, prec, dev, local_rank, st, wu, not args.no_parity, not args.no_device_state))
+            ents.append(config_entry(torch, cname, prec, dev, local_rank, st, wu, not args.no_parity, not args.no_device_state, args.placement_candidates))
         line["configs"] = ents
 
     if world > 1:

@@ -1,0 +1,53 @@
+"""zoic_amd/placement.py: the pair of frame buffers the camera runs fastest on -- same rays whichever pair is kept."""
+import pytest
+
+from zoic_amd import PRECISION_STRICT, ZoicCamera
+from zoic_amd.placement import pick_frame_buffers
+from zoic_amd.workloads import CONFIGS, camera_params
+
+pytestmark = pytest.mark.gpu
+
+
+def camera(cfg):
+    cam = ZoicCamera(0)
+    cam.update(**camera_params(cfg))
+    cam.set_precision(PRECISION_STRICT)
+    return cam
+
+
+def test_the_chosen_pair_holds_the_same_samples_and_gives_the_same_rays(gpu):
+    import torch
+    c = CONFIGS["C2"]
+    n = (1 << 22) + 4096 + 11                      # long enough to probe, ragged
+    cam = camera("C2")
+    s = cam.generate_samples(n, c["width"], c["height"], c["spp"], seed=3, ray_index_base=7)
+    want = cam.create_rays(s, ray_index_base=7)["rays"].clone()
+    s_ref = s.clone()
+    s2, out, info = pick_frame_buffers(cam, s, candidates=2, steps=2, warmup=1, ray_index_base=7)
+    assert info["candidates"] == 2 and info["pairs"] == 4
+    rates = info["rates_mrays_s"]
+    assert len(rates) == 2 and all(len(r) == 2 and all(v > 0 for v in r) for r in rates)
+    bi, bj = info["chosen"]
+    assert rates[bi][bj] == max(max(r) for r in rates) == info["chosen_pair_mrays_s"]
+    assert info["first_pair_mrays_s"] == rates[0][0] and info["slowest_pair_mrays_s"] == min(min(r) for r in rates)
+    assert torch.equal(s2, s_ref)
+    assert out["rays"].shape == (n, 8)
+    cam.create_rays(s2, ray_index_base=7, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out["rays"].view(torch.int32), want.view(torch.int32))      # bit-equal, NaN-safe
+    cam.close()
+
+
+def test_short_frames_and_single_candidates_are_not_probed(gpu):
+    import torch
+    c = CONFIGS["C2"]
+    cam = camera("C2")
+    s = cam.generate_samples(100_000, c["width"], c["height"], c["spp"], seed=1)
+    s2, out, info = pick_frame_buffers(cam, s)
+    assert s2 is s and info["candidates"] == 1 and "rates_mrays_s" not in info and out["rays"].shape == (100_000, 8)
+    big = cam.generate_samples(1 << 22, c["width"], c["height"], c["spp"], seed=1)
+    b2, out, info = pick_frame_buffers(cam, big, candidates=1)
+    assert b2 is big and info["candidates"] == 1 and "rates_mrays_s" not in info
+    with pytest.raises(ValueError):
+        pick_frame_buffers(cam, torch.zeros((8, 4)))
+    cam.close()

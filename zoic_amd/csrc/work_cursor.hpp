@@ -20,10 +20,14 @@
 #ifndef ZOIC_GRID_BLOCKS
 #define ZOIC_GRID_BLOCKS 0ull
 #endif
+#ifndef ZOIC_INTERLEAVED_PARTS
+#define ZOIC_INTERLEAVED_PARTS 0
+#endif
 
 namespace zoic {
 
 constexpr uint32_t kMaxChunkRays = 1024;   // 16 passes of fresh work
+constexpr bool kInterleavedParts = ZOIC_INTERLEAVED_PARTS != 0;
 
 struct WorkGrain { uint32_t chunkRays, chunksPerPart; };
 
@@ -83,7 +87,8 @@ __device__ __forceinline__ bool claim_chunk(unsigned int *__restrict__ workCurso
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(workCursor + part * kCursorPartStride, 1u);
         c = __builtin_amdgcn_readfirstlane(c);
-        begin = (static_cast<uint64_t>(part) * chunksPerPart + c) * chunkRays;
+        begin = kInterleavedParts ? (static_cast<uint64_t>(c) * kCursorParts + part) * chunkRays
+                                  : (static_cast<uint64_t>(part) * chunksPerPart + c) * chunkRays;
         if (c < chunksPerPart && begin < n) break;
         begin = n;                                   // this partition is used up: on to the next one, for good
         part = (part + 1u) % kCursorParts;
