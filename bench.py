@@ -89,7 +89,7 @@ def parse_args():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config array")
     ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-frame (north-star configs 4/5) measurement")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--placement-candidates", type=int, default=3, help="allocations of each frame buffer to choose the pair from (1: the plain first allocations; zoic_amd/placement.py)")
+    ap.add_argument("--placement-candidates", type=int, default=8, help="ray-buffer allocations to choose the frame's from, at most (1: the plain first allocation; zoic_amd/placement.py)")
     ap.add_argument("--no-device-state", action="store_true", help="skip the second of frames with the clock / power sensors read beside it")
     ap.add_argument("--only-headline", action="store_true", help="= --no-configs --no-sharded --no-host-path --no-cpu-baseline --no-parity --no-device-state")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="minimum wall time of one repetition of a CPU baseline leg")
@@ -319,13 +319,13 @@ def max_over_ranks(torch, dist, seconds, dev):
     return float(t.item())
 
 
-def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_rank=0, keep=None, candidates=3):
+def time_frame(torch, cam, cfg, n, base, steps, warmup, dev, dist=None, local_rank=0, keep=None, candidates=8):
     """`steps` launches of one frame of n samples (resident in HBM), bracketed by barrier + synchronize on both sides.
     Returns (elapsed seconds: max over ranks, mean kernel ms by HIP events on the launch stream).
 
-    The frame's two buffers are allocated the way a renderer would allocate them once per session: `candidates` allocations of
-    each, the pair the camera runs fastest on kept (zoic_amd/placement.py -- which allocations hold the sample stream and the
-    ray stream is worth up to 12 % on the headline; `keep["placement"]` has every pair's rate, the plain first pair's included).
+    The frame's ray buffer is allocated the way a renderer would allocate it once per session: up to `candidates` allocations,
+    the one the camera runs fastest on kept (zoic_amd/placement.py -- which allocations hold the sample stream and the ray
+    stream is worth up to 12 % on the headline; `keep["placement"]` has every candidate's rate, the plain first one's included).
     `keep` (a dict) also receives the buffers instead of their being freed (the device_state leg runs on the same pair)."""
     from zoic_amd.placement import pick_frame_buffers
     samples = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=base)
@@ -429,7 +429,7 @@ def frame_stats(counters, n_done):
     return round(counters["vignettedRays"] / max(n_done, 1), 5)
 
 
-def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, parity, device_state=False, candidates=3):
+def config_entry(torch, cfg_name, precision, dev, local_rank, steps, warmup, parity, device_state=False, candidates=8):
     from zoic_amd.workloads import CONFIGS, ray_count
     cfg = CONFIGS[cfg_name]
     n = ray_count(cfg_name)
@@ -849,8 +849,8 @@ def main():
             "zero_weight": frame_stats(counters, counters["succesRays"] + counters["vignettedRays"]),
             "target_mrays_s": round(NORTH_STAR_MRAYS_1GPU * (1.0 if world == 1 else 0.75 * world)),
         }
-        # which allocations hold the frame (zoic_amd/placement.py): every (sample buffer, ray buffer) pair's rate over a few frames
-        # BEFORE the timed region; `first_pair_mrays_s` is what the plain first allocations would have given
+        # which allocation holds the frame's rays (zoic_amd/placement.py): every candidate's rate over a few frames BEFORE the timed
+        # region; `first_pair_mrays_s` is what the plain first allocation would have given
         line["placement"] = keep.get("placement")
         if world == 1 and not args.no_device_state:
             # outside the timed region: what clock did the kernel get?  (the peaks above are at 2.4 GHz; the socket's power limit decides)

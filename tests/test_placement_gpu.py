@@ -23,13 +23,15 @@ def test_the_chosen_pair_holds_the_same_samples_and_gives_the_same_rays(gpu):
     s = cam.generate_samples(n, c["width"], c["height"], c["spp"], seed=3, ray_index_base=7)
     want = cam.create_rays(s, ray_index_base=7)["rays"].clone()
     s_ref = s.clone()
-    s2, out, info = pick_frame_buffers(cam, s, candidates=2, steps=2, warmup=1, ray_index_base=7)
-    assert info["candidates"] == 2 and info["pairs"] == 4
+    s2, out, info = pick_frame_buffers(cam, s, candidates=3, steps=2, warmup=1, ray_index_base=7, spread_stop=1e9)    # never satisfied: all three are tried
+    assert info["candidates"] == 3
     rates = info["rates_mrays_s"]
-    assert len(rates) == 2 and all(len(r) == 2 and all(v > 0 for v in r) for r in rates)
-    bi, bj = info["chosen"]
-    assert rates[bi][bj] == max(max(r) for r in rates) == info["chosen_pair_mrays_s"]
-    assert info["first_pair_mrays_s"] == rates[0][0] and info["slowest_pair_mrays_s"] == min(min(r) for r in rates)
+    assert len(rates) == 3 and all(v > 0 for v in rates)
+    assert rates[info["chosen"]] == max(rates) == info["chosen_pair_mrays_s"]
+    assert info["first_pair_mrays_s"] == rates[0] and info["slowest_pair_mrays_s"] == min(rates) and info["both_classes_seen"] is False
+    assert s2 is s
+    _, _, early = pick_frame_buffers(cam, s, candidates=5, steps=2, warmup=1, ray_index_base=7, spread_stop=0.0)        # satisfied at once: two candidates
+    assert early["candidates"] == 2 and early["both_classes_seen"] is True
     assert torch.equal(s2, s_ref)
     assert out["rays"].shape == (n, 8)
     cam.create_rays(s2, ray_index_base=7, out=out)

@@ -14,7 +14,10 @@ torch.cuda.set_device(0)
 cam = bench.make_camera(name, prec, 0)
 pads, samples, outs = [], [], []
 s0 = cam.generate_samples(n, cfg["width"], cfg["height"], cfg["spp"], seed=1, ray_index_base=0)
+spacer = int(float(os.environ.get("SPACER_GB", "0")) * (1 << 30))
 for i in range(K):
+    if spacer and i > 0:
+        pads.append(torch.empty(spacer, dtype=torch.uint8, device=dev))      # push the next candidates into another region of the device memory
     pads.append(torch.empty((7 + 11 * i) * 1024 * 1024 + 8192, dtype=torch.uint8, device=dev))
     samples.append(s0 if i == 0 else s0.clone())
     pads.append(torch.empty((5 + 3 * i) * 1024 * 1024 + 4096, dtype=torch.uint8, device=dev))
@@ -36,5 +39,6 @@ for s in samples:
         row.append(n * steps / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     vals += row
     print("  " + " ".join("%.2f" % v for v in row), flush=True)
-print("%s %s lib=%s: min %.2f mean %.2f max %.2f Grays/s over %d pairs" % (name, prec, os.path.basename(os.environ.get("ZOIC_AMD_LIB", "default")), min(vals), sum(vals) / len(vals), max(vals), len(vals)))
+print("addresses: samples " + " ".join("%#x" % t.data_ptr() for t in samples) + " | rays " + " ".join("%#x" % o["rays"].data_ptr() for o in outs))
+print("%s %s spacer %s GB lib=%s: min %.2f mean %.2f max %.2f Grays/s over %d pairs" % (name, prec, os.environ.get("SPACER_GB", "0"), os.path.basename(os.environ.get("ZOIC_AMD_LIB", "default")), min(vals), sum(vals) / len(vals), max(vals), len(vals)))
 cam.close()

@@ -6,8 +6,8 @@ every offset of one 240 GB allocation falls into one of a few classes of multi-G
 and a frame whose sample buffer and ray buffer lie in the SAME class runs at 40.9 Grays/s, in different classes at 45.5-46.2:
 the DRAM read latency behind the L2 is 13 % higher when reads and writes mix in one class (TCC_EA0_RDREQ_LEVEL / RDREQ 1638
 against 1444 cycles).  User space cannot ask where an allocation lies, but it can measure: a renderer allocates its frame
-buffers once, so `pick_frame_buffers` allocates a few candidates of each, times the camera's own kernel over every pair for
-a few frames and keeps the fastest pair (the others are freed).  The rays are the same bits whichever pair is kept.
+buffers once, so `pick_frame_buffers` allocates candidate ray buffers one after another, times the camera's own kernel on each for a few
+frames until it has seen both rates, and keeps the fastest (the others are freed).  The rays are the same bits on any buffer.
 
 This is host-side set-up around the C-ABI's device-pointer call (zoic_create_rays_device): nothing in the kernels changes.
 """
@@ -28,48 +28,55 @@ def _pair_rate(torch, camera, samples, out, ray_index_base, steps, warmup):
     return n * steps / max(e0.elapsed_time(e1) * 1e-3, 1e-9)
 
 
-def pick_frame_buffers(camera, samples, candidates=3, steps=4, warmup=2, ray_index_base=0, memory_fraction=0.5, min_samples=1 << 22):
-    """samples: the frame's (n, 4) float32 device tensor.  Returns (samples, out, info): the pair of (sample buffer, ray buffer
-    = dict(rays=(n, 8) float32)) on which `camera` ran fastest out of `candidates` allocations of each, and what was measured
-    (`info["rates_mrays_s"][i][j]`: sample buffer i x ray buffer j; pair (0, 0) is what a plain torch.empty would have given).
+def pick_frame_buffers(camera, samples, candidates=8, steps=4, warmup=2, ray_index_base=0, memory_fraction=0.5, min_samples=1 << 22,
+                       spread_stop=1.09):
+    """samples: the frame's (n, 4) float32 device tensor.  Returns (samples, out, info): `out` = dict(rays=(n, 8) float32) is the ray
+    buffer on which `camera` ran this frame fastest out of up to `candidates` allocations, and `info` what was measured
+    (`info["rates_mrays_s"][j]`: ray buffer j against the sample buffer; j = 0 is what a plain torch.empty would have given).
 
-    Falls back to one candidate -- no probe -- when the frame is too short to time (`min_samples`) or when `candidates` copies of
-    both buffers would not fit into `memory_fraction` of the free device memory."""
+    The relation is between the two buffers' classes of regions, so only the ray buffer is searched.  Candidates are allocated one
+    after another and ALL kept until the end -- a fresh process's allocations come out of the device memory region after region,
+    and adjacent ones usually share a class (one box: 40.9-41.5 on all sixteen pairs of four adjacent candidates of each; in one
+    scan the first 28 GB of an allocation were one class, in another all of 72 GB) -- and the search stops as soon as two rates differ
+    by `spread_stop` (the rates are two-valued, 12 % apart on the image-sampler frame, with values in between for a buffer that straddles two classes: the faster class has been seen), at `candidates`, or when the candidates fill
+    `memory_fraction` of the device memory that was free.  The losers are freed.
+
+    One candidate -- no probe -- when the frame is too short to time (`min_samples`) or a second ray buffer does not fit."""
     import torch
     if not samples.is_cuda:
         raise ValueError("pick_frame_buffers works on device tensors")
     dev = samples.device
     n = samples.shape[0]
-    per_pair = samples.numel() * samples.element_size() + n * 32
-    k = max(1, int(candidates))
-    free = torch.cuda.mem_get_info(dev)[0]
-    while k > 1 and (k * per_pair - samples.numel() * samples.element_size()) > memory_fraction * free:
-        k -= 1
+    ray_bytes = n * 32
+    budget = memory_fraction * torch.cuda.mem_get_info(dev)[0]
+    kmax = max(1, int(candidates))
     if n < min_samples:
-        k = 1
+        kmax = 1
     t0 = time.perf_counter()
-    pads = []
-    sbufs, obufs = [samples], []
-    for i in range(k):
-        if i > 0:
-            # odd-sized spacers: consecutive large allocations of one size tend to come out of one physical region
-            pads.append(torch.empty((7 + 11 * i) * (1 << 20), dtype=torch.uint8, device=dev))
-            sbufs.append(samples.clone())
-            pads.append(torch.empty((5 + 3 * i) * (1 << 20), dtype=torch.uint8, device=dev))
+    obufs, pads, rates = [], [], []
+    info = {"steps": steps}
+    while len(obufs) < kmax and (len(obufs) + 1) * ray_bytes <= max(budget, ray_bytes):
+        j = len(obufs)
+        if j > 0:   # an odd-sized allocation in between: consecutive allocations of one size tend to be carved out of one block
+            pads.append(torch.empty((5 + 6 * j) * (1 << 20), dtype=torch.uint8, device=dev))
         obufs.append(dict(rays=torch.empty((n, 8), dtype=torch.float32, device=dev)))
-    info = {"candidates": k, "pairs": k * k, "steps": steps}
-    if k == 1:
-        info["note"] = "no probe (short frame or not enough free memory for candidates)"
+        if kmax == 1:
+            break
+        rates.append(_pair_rate(torch, camera, samples, obufs[j], ray_index_base, steps, warmup))
+        if j == 1:   # the first candidate was timed cold: once more, warm
+            rates[0] = max(rates[0], _pair_rate(torch, camera, samples, obufs[0], ray_index_base, steps, warmup))
+        if j >= 1 and max(rates) >= spread_stop * min(rates):
+            break
+    info["candidates"] = len(obufs)
+    if len(rates) < 2:
+        info["note"] = "no probe (short frame, one candidate asked for, or no room for a second ray buffer)"
         return samples, obufs[0], info
-    rates = [[_pair_rate(torch, camera, s, o, ray_index_base, steps, warmup) for o in obufs] for s in sbufs]
-    rates[0][0] = max(rates[0][0], _pair_rate(torch, camera, sbufs[0], obufs[0], ray_index_base, steps, warmup))   # the first pair was timed cold: once more, warm
-    best = max(((rates[i][j], i, j) for i in range(k) for j in range(k)))
-    _, bi, bj = best
-    info.update(rates_mrays_s=[[round(r / 1e6, 1) for r in row] for row in rates], chosen=[bi, bj],
-                first_pair_mrays_s=round(rates[0][0] / 1e6, 1), chosen_pair_mrays_s=round(best[0] / 1e6, 1),
-                slowest_pair_mrays_s=round(min(min(row) for row in rates) / 1e6, 1))
-    s_keep, o_keep = sbufs[bi], obufs[bj]
-    del sbufs, obufs, pads
+    bj = max(range(len(rates)), key=lambda j: rates[j])
+    info.update(rates_mrays_s=[round(r / 1e6, 1) for r in rates], chosen=bj, first_pair_mrays_s=round(rates[0] / 1e6, 1),
+                chosen_pair_mrays_s=round(rates[bj] / 1e6, 1), slowest_pair_mrays_s=round(min(rates) / 1e6, 1),
+                both_classes_seen=bool(max(rates) >= spread_stop * min(rates)))
+    o_keep = obufs[bj]
+    del obufs, pads
     torch.cuda.empty_cache()          # hand the losing candidates back to the driver
     info["seconds"] = round(time.perf_counter() - t0, 3)
-    return s_keep, o_keep, info
+    return samples, o_keep, info
