@@ -40,7 +40,7 @@
 #pragma STDC FP_CONTRACT OFF
 
 #ifndef ZOIC_EXP_WHATIF
-#define ZOIC_EXP_WHATIF 0   // TIMING-ONLY experiments (results are WRONG, never shipped; profiles/ab_r06/whatif.log): 1 = the IMAGE kernels' retries sample the
+#define ZOIC_EXP_WHATIF 0   // TIMING-ONLY experiments (results are WRONG, never shipped; profiles/ab_r06/whatif.log; 5 / 6: the record stores, profiles/ab_r06/ab_store_whatif.log): 1 = the IMAGE kernels' retries sample the
                             // disk instead of the image (no retry gathers), 2 = their first try does (no probe gather), 3 = no listed kernel is launched,
                             // 4 = finish_dead_ray does not re-read its sample
 #endif
@@ -245,7 +245,9 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #define ZOIC_POOL_SLIM 0   // 1: 40-byte entries: the exit-pupil scale / translation are looked up again when a ray is popped
 #endif
 #ifndef ZOIC_STORE_TRANSPOSED
-#define ZOIC_STORE_TRANSPOSED 0   // 1: a fresh batch's records leave through an LDS transpose (two contiguous-KB stores per wave)
+#define ZOIC_STORE_TRANSPOSED 2   // a fresh batch's records leave through an LDS transpose (two contiguous-KB stores per wave): 0 never, 1 every kernel, 2 the IMAGE kernels
+                                  // [MI355X: -2 % on the fisheye (round 5: it is instructions on a pipe-bound kernel); on the image-sampler frame, whose waves wait for memory
+                                  // behind the DRAM write stream, +0.3-1 % on a fast pair of buffers and +2.8 % on a slow one: profiles/ab_r06/ab_store_whatif.log]
 #endif
 #if ZOIC_STORE_TRANSPOSED && ZOIC_POOL_SLIM
 #error "ZOIC_STORE_TRANSPOSED stages in the upper half of pool1's float4 array: not with ZOIC_POOL_SLIM"
@@ -696,13 +698,13 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;
             if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
             const uint32_t flags = (tries > 0 ? 1u : 0u) | (tries << 1) | ((lutMiss & 1u) << 6);
-#if ZOIC_STORE_TRANSPOSED
+            constexpr bool kTransposed = (ZOIC_STORE_TRANSPOSED == 1) || (ZOIC_STORE_TRANSPOSED == 2 && IMAGE);
             // Phase A holds 64 CONSECUTIVE rays in lane order and most of them finish here: their records are one contiguous 2 KB
             // block.  store_ray_record writes it as 2 x 64 half-sectors at a 32-byte stride per instruction; transposed through LDS --
             // the upper halves of pool0 / pool1 are free during a fresh batch (poolCnt < 64 and the push comes after this) -- each of
             // the two store instructions writes one contiguous KB (lane j: 16-byte piece j, then 64 + j), with the lanes of unfinished
             // rays masked off.  Phase B's rays are scattered: they keep the per-lane store.
-            if (!fromPool) {
+            if (kTransposed && !fromPool) {
                 float4 *stA = pool0 + 64, *stB = reinterpret_cast<float4 *>(pool1) + 64;
                 stA[lane] = make_float4(o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f);   // zoic.cpp:1960-1961
                 stB[lane] = make_float4(d.y * -1.0f, d.z * -1.0f, w, __builtin_bit_cast(float, flags));
@@ -715,12 +717,19 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
                 if ((fin >> (32u + (lane >> 1))) & 1ull) dst[64u + lane] = p1;
                 __builtin_amdgcn_wave_barrier();
             } else
-#endif
             if (finished) {
+#if ZOIC_EXP_WHATIF == 5
+                const uint32_t at = idx & 0xffffu;   // timing only: every record into one 2 MB window (the write stream never reaches DRAM)
+#else
+                const uint32_t at = idx;
+#endif
                 if constexpr (ZOIC_STORE_NT == 2 || (ZOIC_STORE_NT == 1 && IMAGE))
-                    store_ray_record_nt(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);
-                else store_ray_record(out, idx, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);   // zoic.cpp:1960-1961
+                    store_ray_record_nt(out, at, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);
+                else store_ray_record(out, at, o.x * -1.0f, o.y * -1.0f, o.z * -1.0f, d.x * -1.0f, d.y * -1.0f, d.z * -1.0f, w, flags);   // zoic.cpp:1960-1961
             }
+#if ZOIC_EXP_WHATIF == 6
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // timing only: vmcnt(0) right behind the record stores -- are their acknowledgements what a later wait pays for?
+#endif
         }
         ZOIC_MARK(7)   // finish: counters + record store
         if constexpr (GUARD) {
