@@ -245,9 +245,10 @@ static __device__ unsigned long long g_regionCycles[16];   // s_memtime cycles p
 #define ZOIC_POOL_SLIM 0   // 1: 40-byte entries: the exit-pupil scale / translation are looked up again when a ray is popped
 #endif
 #ifndef ZOIC_STORE_TRANSPOSED
-#define ZOIC_STORE_TRANSPOSED 2   // a fresh batch's records leave through an LDS transpose (two contiguous-KB stores per wave): 0 never, 1 every kernel, 2 the IMAGE kernels
+#define ZOIC_STORE_TRANSPOSED 2   // a fresh batch's records leave through an LDS transpose (two contiguous-KB stores per wave): 0 never, 1 every kernel, 2 the FAST IMAGE kernels
                                   // [MI355X: -2 % on the fisheye (round 5: it is instructions on a pipe-bound kernel); on the image-sampler frame, whose waves wait for memory
                                   // behind the DRAM write stream, +0.3-1 % on a fast pair of buffers and +2.8 % on a slow one: profiles/ab_r06/ab_store_whatif.log]
+                                  // [everywhere (=1), profiles/ab_r06/ab_transposed_configs.log: C2 -1.4 %, C4 -2.5 %, STRICT C3 -0.6 %, C5 +1.6 % (same kernel as C4's: it would need its own instantiation)]
 #endif
 #if ZOIC_STORE_TRANSPOSED && ZOIC_POOL_SLIM
 #error "ZOIC_STORE_TRANSPOSED stages in the upper half of pool1's float4 array: not with ZOIC_POOL_SLIM"
@@ -698,7 +699,7 @@ __device__ __forceinline__ void kolb_pool_body(const KolbTable &T, const BokehTa
             float w = (tries > static_cast<uint32_t>(kMaxTries)) ? 0.0f : 1.0f;
             if (T.exposureOn) w *= T.exposureMul;                                            // zoic.cpp:1981-1987
             const uint32_t flags = (tries > 0 ? 1u : 0u) | (tries << 1) | ((lutMiss & 1u) << 6);
-            constexpr bool kTransposed = (ZOIC_STORE_TRANSPOSED == 1) || (ZOIC_STORE_TRANSPOSED == 2 && IMAGE);
+            constexpr bool kTransposed = (ZOIC_STORE_TRANSPOSED == 1) || (ZOIC_STORE_TRANSPOSED == 2 && IMAGE && !STRICT);
             // Phase A holds 64 CONSECUTIVE rays in lane order and most of them finish here: their records are one contiguous 2 KB
             // block.  store_ray_record writes it as 2 x 64 half-sectors at a 32-byte stride per instruction; transposed through LDS --
             // the upper halves of pool0 / pool1 are free during a fresh batch (poolCnt < 64 and the push comes after this) -- each of
