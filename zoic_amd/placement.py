@@ -39,7 +39,7 @@ def pick_frame_buffers(camera, samples, candidates=8, steps=4, warmup=2, ray_ind
     and adjacent ones usually share a class (one box: 40.9-41.5 on all sixteen pairs of four adjacent candidates of each; in one
     scan the first 28 GB of an allocation were one class, in another all of 72 GB) -- and the search stops as soon as two rates differ
     by `spread_stop` (the rates are two-valued, 12 % apart on the image-sampler frame, with values in between for a buffer that straddles two classes: the faster class has been seen), at `candidates`, or when the candidates fill
-    `memory_fraction` of the device memory that was free.  The losers are freed.
+    `memory_fraction` of the device memory that was free.  From the fifth candidate on a growing spacer allocation (4, 8, 16 ... ray buffers, within the same budget) is put in front of each.  The losers are freed.
 
     One candidate -- no probe -- when the frame is too short to time (`min_samples`) or a second ray buffer does not fit."""
     import torch
@@ -55,11 +55,20 @@ def pick_frame_buffers(camera, samples, candidates=8, steps=4, warmup=2, ray_ind
     t0 = time.perf_counter()
     obufs, pads, rates = [], [], []
     info = {"steps": steps}
-    while len(obufs) < kmax and (len(obufs) + 1) * ray_bytes <= max(budget, ray_bytes):
+    held = 0                                  # bytes this search holds: candidates + spacers
+    while len(obufs) < kmax and held + ray_bytes <= max(budget, ray_bytes):
         j = len(obufs)
         if j > 0:   # an odd-sized allocation in between: consecutive allocations of one size tend to be carved out of one block
             pads.append(torch.empty((5 + 6 * j) * (1 << 20), dtype=torch.uint8, device=dev))
+        if j >= 4:
+            # four adjacent candidates alike: reach further -- a spacer of 4, 8, 16, ... ray buffers (kept until the end, cut to the budget) before
+            # the next one.  One class of regions was seen to run for 28 GB of an allocation, on another box for all of 72 GB.
+            spacer = int(min((1 << (j - 2)) * ray_bytes, budget - held - ray_bytes)) >> 21 << 21
+            if spacer > 0:
+                pads.append(torch.empty(spacer, dtype=torch.uint8, device=dev))
+                held += spacer
         obufs.append(dict(rays=torch.empty((n, 8), dtype=torch.float32, device=dev)))
+        held += ray_bytes
         if kmax == 1:
             break
         rates.append(_pair_rate(torch, camera, samples, obufs[j], ray_index_base, steps, warmup))
@@ -68,6 +77,7 @@ def pick_frame_buffers(camera, samples, candidates=8, steps=4, warmup=2, ray_ind
         if j >= 1 and max(rates) >= spread_stop * min(rates):
             break
     info["candidates"] = len(obufs)
+    info["held_gb"] = round(held / 2 ** 30, 1)          # candidates + spacers at the search's end
     if len(rates) < 2:
         info["note"] = "no probe (short frame, one candidate asked for, or no room for a second ray buffer)"
         return samples, obufs[0], info
